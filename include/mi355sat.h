@@ -1,0 +1,157 @@
+/*
+ * mi355sat.h — C ABI of the MI355X-native SAT solve loop (libmi355sat.so).
+ *
+ * This is the drop-in boundary behind timberborn_support_solver's solver
+ * backend.  The reference is generic over `S: Solve + Interrupt (+ Default +
+ * SolveStats) + Send + 'static` and instantiates it with
+ * `rustsat_glucose::simp::Glucose`:
+ *
+ *   crates/repl/src/solver_runner.rs:8-20   run_solver<S>: add_cnf, interrupter, solve
+ *   crates/repl/src/main.rs:17,295          GlucoseSimp::default()
+ *   crates/repl/src/main.rs:329,363         full_solution(), stats()
+ *   crates/gui/src/solver_backend.rs:69-97  S::default(), add_cnf, interrupter, solve
+ *   crates/gui/src/main.rs:2,26             App::<GlucoseSimp>
+ *
+ * rustsat-glucose talks to its C++ solver through an IPASIR-shaped C API
+ * (init / add / solve / val / interrupt / release; solve returns 10/20/0).
+ * The functions below have the same shape so that a Rust `Solve` impl over
+ * this library is a thin clone of that wrapper.
+ *
+ * Conventions
+ *   - literals are IPASIR/DIMACS: +v / -v, v >= 1; 0 terminates a clause in
+ *     mi355sat_add().  (rustsat `Lit` = (idx<<1)|neg with 0-based idx maps to
+ *     ±(idx+1).)
+ *   - no exceptions cross the ABI; errors are negative return codes and
+ *     mi355sat_last_error() gives the text.
+ *   - a handle may be moved between OS threads between calls
+ *     (solver_runner.rs:15 moves the solver into tokio's blocking pool); every
+ *     entry point binds its device itself.  The ONLY function that may run
+ *     concurrently with another call on the same handle is
+ *     mi355sat_interrupt() (main.rs:310-317 calls it from another task while
+ *     solve() runs).
+ *   - clause memory is copied on add; the caller may free it immediately
+ *     (add_cnf consumes its argument, solver_runner.rs:12).
+ *   - there is NO CPU fallback: if no HIP device is usable, mi355sat_new()
+ *     returns NULL and mi355sat_last_error(NULL) says why.
+ */
+#ifndef MI355SAT_H
+#define MI355SAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355SAT_SAT 10
+#define MI355SAT_UNSAT 20
+#define MI355SAT_INTERRUPTED 0
+#define MI355SAT_ERR_OOM (-1)
+#define MI355SAT_ERR_HIP (-2)
+#define MI355SAT_ERR_STATE (-3)
+#define MI355SAT_ERR_ARG (-4)
+
+typedef struct mi355sat mi355sat;
+
+/* Options for mi355sat_new(); zero-initialise and set what you need.
+ * A NULL pointer means all defaults. */
+typedef struct mi355sat_opts {
+    int32_t device;            /* HIP device ordinal; -1 = current device (default 0) */
+    int32_t workers;           /* concurrent search workers (one wavefront each) for a plain
+                                  solve(); 0 = default */
+    int64_t conflict_budget;   /* per-solve conflict limit summed over workers; 0 = none.
+                                  Exhausted budget -> MI355SAT_INTERRUPTED */
+    int32_t slice_conflicts;   /* conflicts per worker per kernel launch; 0 = default */
+    uint64_t seed;             /* diversification seed (phases / decision order of workers > 0) */
+    int32_t verbose;           /* 0 quiet, 1 progress on stderr */
+    int32_t reserved[8];
+} mi355sat_opts;
+
+/* Counters.  n_deq .. n_enq are the five event counters of SURVEY.md §8(d)
+ * from which algorithmic bytes are computed:
+ *   bytes_alg = 12*n_deq + 9*n_watch + 5*n_cl_lit + 8*n_move + 13*n_enq      */
+typedef struct mi355sat_stats_t {
+    uint64_t propagations;     /* trail literals dequeued by BCP (== n_deq) */
+    uint64_t decisions;
+    uint64_t conflicts;
+    uint64_t restarts;
+    uint64_t learnts;          /* learnt clauses currently kept (sum over workers) */
+    uint64_t learnt_literals;
+    uint64_t reduce_dbs;
+    uint64_t n_clauses;        /* clauses added by the caller (rustsat SolverStats.n_clauses) */
+    uint64_t max_var;          /* highest variable index seen, 1-based (0 = none) */
+    double   avg_clause_len;
+    double   solve_seconds;    /* wall-clock inside solve()/solve_batch()/propagate_batch() */
+    double   kernel_seconds;   /* device time of the search / BCP kernels (HIP events) */
+    uint64_t kernel_launches;
+    uint64_t n_deq, n_watch, n_cl_lit, n_move, n_enq;
+    uint64_t n_sat, n_unsat, n_terminated; /* rustsat SolverStats: results returned so far */
+    uint64_t reserved[8];
+} mi355sat_stats_t;
+
+/* --- lifecycle (Default::default / Drop) --------------------------------- */
+mi355sat* mi355sat_new(const mi355sat_opts* opts);
+void mi355sat_free(mi355sat* s);
+const char* mi355sat_signature(void);                 /* Solve::signature */
+const char* mi355sat_last_error(const mi355sat* s);   /* s may be NULL (error of the last failed new) */
+
+/* --- clause input (Solve::add_cnf / add_clause_ref) ---------------------- */
+/* Bulk CSR: clause i = lits[offsets[i] .. offsets[i+1]), offsets has n_clauses+1 entries. */
+int mi355sat_add_cnf(mi355sat* s, const int32_t* lits, const uint64_t* offsets, uint64_t n_clauses);
+/* IPASIR-style incremental add: literals, then 0 to close the clause. */
+int mi355sat_add(mi355sat* s, int32_t lit_or_0);
+/* Make sure variables 1..n exist even if they occur in no clause (rustsat reserve). */
+int mi355sat_reserve(mi355sat* s, uint64_t n_vars);
+
+/* --- solve (Solve::solve) ------------------------------------------------- */
+/* Returns MI355SAT_SAT / MI355SAT_UNSAT / MI355SAT_INTERRUPTED or a negative error. */
+int mi355sat_solve(mi355sat* s);
+
+/* Batched solve under assumptions: instance i = formula AND assumption literals
+ * assumps[assump_offsets[i] .. assump_offsets[i+1]).  This is what the sharded
+ * decreasing-k sweep uses: the clause database (base CNF + one totalizer built
+ * for k_max) is uploaded once and instance i assumes the negated totalizer
+ * output for its own bound (solver_loop, crates/repl/src/main.rs:290-346, solves
+ * one fresh CNF per k; the k's are independent).  results[i] receives
+ * 10/20/0.  If stop_at_first != 0 the call returns as soon as one instance has a
+ * verdict (others report 0).  Returns 0 or a negative error. */
+int mi355sat_solve_batch(mi355sat* s, const int32_t* assumps, const uint64_t* assump_offsets,
+                         uint64_t n_instances, int32_t* results, int stop_at_first);
+
+/* Batched unit propagation (BCP only, no search): instance i enqueues its
+ * decision literals one decision level at a time, propagating to fixpoint after
+ * each, and stops at the first conflict.  out_conflict[i] = 0 (fixpoint) or 1.
+ * out_values (may be NULL) is n_instances rows of n_vars bytes:
+ * 1 true, -1 false, 0 unassigned; for a conflicting instance the row holds the
+ * assignment at the moment the conflict was found and is not comparable.
+ * out_trail_len[i] (may be NULL) = number of assigned literals.
+ * `repeat` > 1 re-runs the same batch that many times inside the call (device
+ * state reset each time) for timing.  Returns 0 or a negative error. */
+int mi355sat_propagate_batch(mi355sat* s, const int32_t* decisions, const uint64_t* decision_offsets,
+                             uint64_t n_instances, int8_t* out_values, uint64_t n_vars,
+                             int32_t* out_conflict, int32_t* out_trail_len, int32_t repeat);
+
+/* --- model (Solve::lit_val / full_solution) ------------------------------ */
+/* After SAT: returns +lit if lit is true, -lit if false, 0 if unknown var / no model. */
+int32_t mi355sat_val(mi355sat* s, int32_t lit);
+/* Bulk model: out[v-1] = 1 / -1 (0 for a variable the solver never saw). */
+int mi355sat_model(mi355sat* s, int8_t* out, uint64_t n_vars);
+/* Model of instance i of the last mi355sat_solve_batch(). */
+int mi355sat_model_of(mi355sat* s, uint64_t instance, int8_t* out, uint64_t n_vars);
+
+/* --- Interrupt::interrupter / InterruptSolver::interrupt ------------------ */
+/* Async, thread-safe, idempotent: only sets a flag that solve() polls between
+ * kernel launches (and the kernels poll from pinned host memory). */
+void mi355sat_interrupt(mi355sat* s);
+
+/* --- SolveStats::stats ----------------------------------------------------- */
+int mi355sat_stats(const mi355sat* s, mi355sat_stats_t* out);
+
+/* Optional DRUP-style log of learnt clauses of worker 0 (debug / UNSAT checking on
+ * small instances).  Must be called before solve().  path NULL disables. */
+int mi355sat_set_proof_path(mi355sat* s, const char* path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355SAT_H */
