@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — literal-propagations/s of the MI355X-native SAT solve loop on the
+BASELINE.json headline workload (rect 64x64, decreasing-k sweep at the
+first-UNSAT bound, default platform set).
+
+One *step* = one slice of the search kernel over this GPU's batch of (k, seed)
+instances: every worker (one wavefront) advances its own CDCL search by
+`--slice` conflicts.  Inputs (clause database, worker slabs) are resident in HBM
+before the timed region.  Multi-GPU: one process per GPU; the (k, seed) instances
+are independent, so ranks shard the seeds with no data-path collective and only
+exchange the SAT/UNSAT cut (min SAT count, max UNSAT k: one tiny all-reduce per
+step over RCCL) — weak scaling.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes
+(12*n_deq + 9*n_watch + 5*n_cl_lit + 8*n_move + 13*n_enq) divided by
+the search kernel's device time measured with HIP events on its own stream.
+`cpu_baseline` = the oracle's single-thread CDCL restatement ("port": the real
+rustsat-glucose cannot be built here) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=64, help="rect SIZE x SIZE")
+    ap.add_argument("--k-lo", type=int, default=44)
+    ap.add_argument("--k-hi", type=int, default=51)
+    ap.add_argument("--workers", type=int, default=2048, help="wavefront workers per GPU")
+    ap.add_argument("--slice", type=int, default=100, help="conflicts per worker per step")
+    ap.add_argument("--cpu-conflicts", type=int, default=20000, help="conflict budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--platforms", default="default", choices=["default", "1x1"])
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the solver has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from timberborn_support_solver_amd import (PLATFORMS_DEFAULT, Encoding, Mi355Sat, PlatformLimits, SolverResult,
+                                               WorldGrid, algorithmic_bytes)
+
+    n = args.size
+    grid = WorldGrid.rect(n, n)
+    defs = PLATFORMS_DEFAULT if args.platforms == "default" else [(1, 1)]
+    enc = Encoding.encode(defs, grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): args.k_hi}), sweep=True)
+    outs = cnf.card_outputs
+    ks = list(range(args.k_hi, args.k_lo - 1, -1))  # descending sweep
+    # bound k < k_hi is the assumption "NOT at-least-(k+1)"; k_hi itself is already a unit in the CNF
+    assumption_sets = [([-int(outs[k])] if k < args.k_hi else []) for k in ks]
+    workers = max(len(ks), args.workers // len(ks) * len(ks))
+
+    solver = Mi355Sat(device=local_rank, workers=workers, slice_conflicts=args.slice, seed=1000 + rank)
+    solver.add_cnf(cnf.lits, cnf.offsets)
+    solver.reserve(cnf.n_vars)
+    solver.sweep_begin(assumption_sets)  # upload + replicate: everything resident in HBM from here on
+
+    def exchange_cut(results):
+        """The only cross-GPU traffic of the path: (min SAT k, max UNSAT k) over all ranks."""
+        sat_k = min([k for k, r in zip(ks, results) if r == SolverResult.Sat], default=1 << 30)
+        unsat_k = max([k for k, r in zip(ks, results) if r == SolverResult.Unsat], default=-1)
+        if dist is not None:
+            t = torch.tensor([-sat_k, unsat_k], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sat_k, unsat_k = -int(t[0]), int(t[1])
+        return sat_k, unsat_k
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res, _ = solver.sweep_step()
+        exchange_cut(res)
+    st0 = solver.stats()
+    barrier()
+    t0 = time.perf_counter()
+    decided = 0
+    for _ in range(args.steps):
+        res, decided = solver.sweep_step()
+        cut = exchange_cut(res)
+    barrier()
+    dt = time.perf_counter() - t0
+    st1 = solver.stats()
+
+    d = {k: st1[k] - st0[k] for k in ("propagations", "conflicts", "decisions", "n_deq", "n_watch", "n_cl_lit",
+                                      "n_move", "n_enq", "kernel_seconds", "kernel_launches")}
+    props = d["propagations"]
+    alg_bytes = algorithmic_bytes(d)
+    tot = [float(props), dt, float(d["conflicts"])]
+    if dist is not None:
+        t = torch.tensor([float(props), float(d["conflicts"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tm = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        tot = [float(t[0]), float(tm[0]), float(t[1])]
+    total_props, max_dt, total_confl = tot
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        from oracle import oracle as ora
+        o = ora.OracleSolver()
+        o.add_cnf(cnf.lits, cnf.offsets)
+        k_cpu = ks[-1]
+        tc = time.perf_counter()
+        o.solve(assumption_sets[-1], conflict_budget=args.cpu_conflicts)
+        dtc = time.perf_counter() - tc
+        so = o.stats()
+        cpu = {"value": so["propagations"] / max(dtc, 1e-9), "unit": "propagations/s", "cores": 1, "kind": "port",
+               "sample": f"rect {n}x{n} {args.platforms}, at-most-{k_cpu}, first {so['conflicts']} conflicts "
+                         f"({dtc:.1f} s) of the oracle's single-thread CDCL restatement (not rustsat-glucose)",
+               "conflicts_per_s": so["conflicts"] / max(dtc, 1e-9)}
+
+    solver.sweep_end()
+    solver.close()
+    if rank == 0:
+        kern_s = d["kernel_seconds"]
+        launches = max(1, d["kernel_launches"])
+        achieved = alg_bytes / max(kern_s, 1e-9) / 1e9
+        out = {
+            "metric": "literal-propagations/sec + wall-clock to first UNSAT, 64x64 rect",
+            "value": total_props / max_dt,
+            "unit": "propagations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": max_dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": f"rect {n} {n} k-sweep at the first-UNSAT bound: at-most-k for k={args.k_hi}..{args.k_lo}, "
+                                   f"{args.platforms} platforms, one totalizer CNF shared by all k",
+                       "vars": int(cnf.n_vars), "clauses": int(cnf.n_clauses), "literals": int(len(cnf.lits)),
+                       "workers_per_gpu": workers, "instances_per_gpu": len(ks), "slice_conflicts": args.slice,
+                       "parallelism": f"{world} GPU(s) x {workers} wavefront workers, seeds sharded over ranks"},
+            "conflicts_per_s": total_confl / max_dt,
+            "decided_instances": int(decided),
+            "first_unsat_wall_clock_s": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ms_search_kernel", "kernel_ms_avg": kern_s / launches * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes / launches,
+                         "bytes_per_propagation": alg_bytes / max(1, props)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,7 +64,9 @@ typedef struct mi355sat_opts {
     int32_t slice_conflicts;   /* conflicts per worker per kernel launch; 0 = default */
     uint64_t seed;             /* diversification seed (phases / decision order of workers > 0) */
     int32_t verbose;           /* 0 quiet, 1 progress on stderr */
-    int32_t reserved[8];
+    int32_t reduce_first;      /* conflicts before the first learnt-clause reduction; 0 = 2000 */
+    int32_t reduce_inc;        /* growth of the reduction interval; 0 = 300 */
+    int32_t reserved[6];
 } mi355sat_opts;
 
 /* Counters.  n_deq .. n_enq are the five event counters of SURVEY.md §8(d)
@@ -117,6 +119,14 @@ int mi355sat_solve(mi355sat* s);
  * verdict (others report 0).  Returns 0 or a negative error. */
 int mi355sat_solve_batch(mi355sat* s, const int32_t* assumps, const uint64_t* assump_offsets,
                          uint64_t n_instances, int32_t* results, int stop_at_first);
+
+/* The same batch, one kernel slice at a time (what bench.py times): begin uploads
+ * the formula and creates the workers, each step runs every worker for
+ * `slice_conflicts` conflicts (or to its verdict) and refreshes results / stats,
+ * end fetches the models of SAT instances (mi355sat_model_of) and drops the batch. */
+int mi355sat_sweep_begin(mi355sat* s, const int32_t* assumps, const uint64_t* assump_offsets, uint64_t n_instances);
+int mi355sat_sweep_step(mi355sat* s, int32_t* results /* may be NULL */, uint64_t* n_decided /* may be NULL */);
+int mi355sat_sweep_end(mi355sat* s);
 
 /* Batched unit propagation (BCP only, no search): instance i enqueues its
  * decision literals one decision level at a time, propagating to fixpoint after

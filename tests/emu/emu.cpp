@@ -1,0 +1,117 @@
+// TEST INFRASTRUCTURE ONLY — wavefront emulator runtime (see hip_shim.h).
+#include <chrono>
+
+#include "hip_shim.h"
+
+double emu_now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+namespace emu {
+thread_local Idx t_threadIdx{0, 0, 0}, t_blockIdx{0, 0, 0}, t_blockDim{1, 1, 1};
+
+namespace {
+constexpr int kLanes = 64;
+constexpr size_t kStack = 512 * 1024;
+struct Sched {
+    ucontext_t main_ctx;
+    ucontext_t ctx[kLanes];
+    char* stacks[kLanes] = {nullptr};
+    int state[kLanes];   // 0 runnable, 1 waiting at a rendezvous, 2 done
+    int site[kLanes];
+    void* ra[kLanes];
+    uint64_t buf[2][kLanes];
+    int par[kLanes];
+    int gen = 0;
+    int cur = -1;
+    bool wave_mode = false;
+    const std::function<void()>* body = nullptr;
+};
+thread_local Sched* g = nullptr;
+
+void fiber_entry() {
+    (*g->body)();
+    g->state[g->cur] = 2;
+    swapcontext(&g->ctx[g->cur], &g->main_ctx);
+}
+
+void rendezvous(uint64_t contribution, int site, void* ra) {
+    if (!g || !g->wave_mode) {
+        fprintf(stderr, "emu: wave collective outside a 64-lane launch\n");
+        abort();
+    }
+    int lane = g->cur;
+    g->par[lane] = g->gen & 1;
+    g->buf[g->par[lane]][lane] = contribution;
+    g->site[lane] = site;
+    g->ra[lane] = ra;
+    g->state[lane] = 1;
+    swapcontext(&g->ctx[lane], &g->main_ctx);
+    // resumed: every lane has arrived
+}
+}  // namespace
+
+__attribute__((noinline)) void collective_begin(uint64_t contribution, int site) { rendezvous(contribution, site, __builtin_return_address(0)); }
+uint64_t collective_read(int lane) { return g->buf[g->par[g->cur]][lane & 63]; }
+__attribute__((noinline)) void fence_rendezvous() {
+    if (g && g->wave_mode) rendezvous(0, 99, __builtin_return_address(0));
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    Sched* prev = g;
+    static thread_local Sched sched;
+    g = &sched;
+    g->body = &body;
+    t_blockDim = Idx{block.x, block.y, block.z};
+    for (unsigned b = 0; b < grid.x; b++) {
+        t_blockIdx = Idx{b, 0, 0};
+        if (block.x != (unsigned)kLanes) {
+            g->wave_mode = false;
+            for (unsigned t = 0; t < block.x; t++) {
+                t_threadIdx = Idx{t, 0, 0};
+                body();
+            }
+            continue;
+        }
+        g->wave_mode = true;
+        for (int l = 0; l < kLanes; l++) {
+            if (!g->stacks[l]) g->stacks[l] = (char*)malloc(kStack);
+            getcontext(&g->ctx[l]);
+            g->ctx[l].uc_stack.ss_sp = g->stacks[l];
+            g->ctx[l].uc_stack.ss_size = kStack;
+            g->ctx[l].uc_link = &g->main_ctx;
+            makecontext(&g->ctx[l], fiber_entry, 0);
+            g->state[l] = 0;
+        }
+        for (;;) {
+            int n_done = 0, n_wait = 0, first_site = -1;
+            bool mismatch = false;
+            for (int l = 0; l < kLanes; l++) {
+                if (g->state[l] == 2) { n_done++; continue; }
+                g->cur = l;
+                t_threadIdx = Idx{(unsigned)l, 0, 0};
+                g->state[l] = 0;
+                swapcontext(&g->main_ctx, &g->ctx[l]);
+                if (g->state[l] == 2) { n_done++; continue; }
+                n_wait++;
+                if (first_site < 0) first_site = g->site[l];
+                else if (first_site != g->site[l]) mismatch = true;
+            }
+            if (n_done == kLanes) break;
+            if (n_done != 0 && n_wait != 0) {
+                fprintf(stderr, "emu: %d lanes left the kernel while %d wait at a collective (site %d)\n", n_done, n_wait, first_site);
+                abort();
+            }
+            if (mismatch) {
+                fprintf(stderr, "emu: lanes are at different collectives (divergent wave-level call); block %u sites:", b);
+                for (int l = 0; l < kLanes; l++) fprintf(stderr, " %d@%p", g->state[l] == 2 ? -1 : g->site[l], g->ra[l]);
+                fprintf(stderr, "\n");
+                abort();
+            }
+            g->gen++;
+        }
+        g->wave_mode = false;
+    }
+    g = prev;
+}
+}  // namespace emu

@@ -1,0 +1,85 @@
+"""Shared helpers for the test-suite (test infrastructure)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+VERDICTS = golden("verdicts.json")
+
+
+def terrain_rows(name):
+    if name.startswith("rect"):
+        w, h = (int(v) for v in name[4:].split("x"))
+        return ["X" * w] * h
+    return VERDICTS["terrains"][name]
+
+
+def make_grid(name):
+    from timberborn_support_solver_amd import WorldGrid
+    return WorldGrid.from_rows(terrain_rows(name))
+
+
+def platform_defs(pset):
+    from timberborn_support_solver_amd import PLATFORMS_DEFAULT
+    return PLATFORMS_DEFAULT if pset == "default" else [(1, 1)]
+
+
+_emu = None
+
+
+def emu_lib():
+    """The wavefront-emulator build of the solver library (tests/emu): CPU-side logic tests only."""
+    global _emu
+    if _emu is None:
+        import subprocess
+        d = os.path.join(ROOT, "tests", "emu")
+        subprocess.check_call(["make", "-C", d, "libmi355sat_emu.so"], stdout=subprocess.DEVNULL)
+        _emu = ctypes.CDLL(os.path.join(d, "libmi355sat_emu.so"))
+    return _emu
+
+
+def splitmix64(seed):
+    z = seed & (2 ** 64 - 1)
+    while True:
+        z = (z + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        x = z
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        yield x ^ (x >> 31)
+
+
+def scripted_decisions(enc, grid, seed, n_decisions, p_positive=0.35):
+    """Seeded decision scripts over platform variables: mostly negative
+    literals (a positive 5x5 forces a lot), so that many scripts reach a fixpoint."""
+    g = splitmix64(seed)
+    dims = enc.platform_dims()
+    dec = []
+    for _ in range(n_decisions):
+        r = next(g)
+        x, y = (r >> 8) % grid.width, (r >> 24) % grid.height
+        d = dims[(r >> 40) % len(dims)]
+        v = enc.platform_var(int(x), int(y), d)
+        pos = ((r >> 52) % 1000) < int(1000 * p_positive)
+        dec.append(v if pos else -v)
+    return dec
+
+
+def check_sat_answer(cnf, model, enc, grid, k):
+    """A SAT answer is right iff the model satisfies every clause, the layout validates and has <= k platforms."""
+    from oracle import oracle as ora
+    from timberborn_support_solver_amd import PlatformLayout
+    assert ora.check_model(cnf.lits, cnf.offsets, model) == -1
+    lay = PlatformLayout.from_assignment(model[:enc.n_vars], enc)
+    assert lay.validate(grid).is_valid()
+    assert lay.platform_count() <= k
+    return lay

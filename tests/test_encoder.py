@@ -1,0 +1,118 @@
+"""Host-side encoder mirror (C++) against the oracle restatement and the golden counts.
+Reference under test: Encoding::encode / with_limits (src/encoder.rs:435-667)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from helpers import golden, make_grid, platform_defs
+from oracle import encoder_oracle as eo
+from timberborn_support_solver_amd import (PLATFORMS_DEFAULT, EncoderError, Encoding, PlatformLimits, WorldGrid)
+
+COUNTS = golden("cnf_counts.json")
+
+
+@pytest.mark.parametrize("row", COUNTS["counts"], ids=lambda r: f"{r['terrain']}-{r['platforms']}")
+def test_base_cnf_counts_match_survey_table(row):
+    enc = Encoding.encode(platform_defs(row["platforms"]), make_grid(row["terrain"]))
+    cnf = enc.base_cnf()
+    assert (cnf.n_vars, cnf.n_clauses, len(cnf.lits)) == (row["V"], row["C"], row["L"])
+
+
+def test_family_breakdown_and_edge_sets():
+    enc = Encoding.encode(PLATFORMS_DEFAULT, make_grid("rect8x8"))
+    assert enc.family_counts() == COUNTS["families_rect8x8_default"]
+    assert len(enc.platform_edges_reduced()) == COUNTS["platform_edges_default"]
+    assert len(enc.point_platform_edges_reduced()) == COUNTS["point_edges_default"]
+    # diagram of src/encoder.rs:45-51
+    edges = set(enc.platform_edges_reduced())
+    for a, b in [((1, 1), (1, 2)), ((1, 5), (1, 6)), ((1, 3), (3, 3)), ((3, 1), (3, 3)), ((3, 3), (5, 5)),
+                 ((1, 5), (5, 5)), ((5, 1), (5, 5)), ((1, 1), (2, 1))]:
+        assert (a, b) in edges
+    assert enc.platform_dims() == sorted(set(PLATFORMS_DEFAULT) | {(h, w) for w, h in PLATFORMS_DEFAULT})
+
+
+@pytest.mark.parametrize("terrain,pset", [("ex1", "default"), ("ex1", "1x1"), ("ex2", "default"), ("ex3", "default"),
+                                          ("ex3", "1x1"), ("rect8x8", "default"), ("rect16x16", "default"),
+                                          ("rect5x9", "default"), ("rect1x1", "default"), ("rect7x2", "1x1")])
+def test_product_encoder_equals_oracle_restatement_bit_exact(terrain, pset):
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    o = eo.Encoding(platform_defs(pset), eo.grid_from_rows(grid.rows()))
+    assert enc.n_vars == o.n_vars
+    assert enc.base_cnf().clauses() == o.clauses          # same numbering, same order
+    assert enc.platform_edges_reduced() == [(tuple(a), tuple(b)) for a, b in o.plat_edges]
+    assert enc.point_platform_edges_reduced() == [(tuple(a), tuple(b)) for a, b in o.point_edges]
+    for k in (0, 1, 3, 7, 10 ** 6):
+        cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+        cl, nv, cards = o.with_limits({(1, 1): k})
+        ocnf, onv, _ = eo.into_cnf(cl, nv, cards)
+        assert cnf.clauses() == ocnf and cnf.n_vars == onv
+
+
+def test_other_platform_sets_and_rectangular_limits():
+    grid = make_grid("rect6x5")
+    defs = [(1, 1), (1, 2), (2, 2), (2, 3)]
+    enc = Encoding.encode(defs, grid)
+    o = eo.Encoding(defs, eo.grid_from_rows(grid.rows()))
+    assert enc.base_cnf().clauses() == o.clauses
+    # a non-square type is limited through fresh per-tile "either orientation" vars (encoder.rs:629-641)
+    lim = {(1, 2): 2, (1, 1): 5}
+    cnf = enc.with_limits_into_cnf(PlatformLimits(lim))
+    cl, nv, cards = o.with_limits(lim)
+    ocnf, onv, _ = eo.into_cnf(cl, nv, cards)
+    assert cnf.clauses() == ocnf and cnf.n_vars == onv
+
+
+def test_limit_errors_follow_the_repl():
+    enc = Encoding.encode(PLATFORMS_DEFAULT, make_grid("rect4x4"))
+    with pytest.raises(EncoderError, match="no platform with dimensions `2x2` found"):
+        enc.with_limits_into_cnf(PlatformLimits({(2, 2): 1}))
+    with pytest.raises(EncoderError):
+        Encoding.encode([(1, 2)], make_grid("rect4x4"))   # overlap clauses assume a 1x1 type (encoder.rs:564)
+
+
+def test_world_grid_parsing_rules():
+    g = WorldGrid.from_rows(["XX", "X", "  X"])
+    assert (g.width, g.height) == (3, 3) and g.cells.tolist() == [[1, 1, 0], [1, 0, 0], [0, 0, 1]]
+    with pytest.raises(EncoderError):
+        WorldGrid.from_rows(["X.X"])                      # '.' of the old README is rejected (world.rs:57-60)
+    with pytest.raises(EncoderError):
+        WorldGrid.from_rows([])
+
+
+def test_toml_reader(tmp_path):
+    p = tmp_path / "t.toml"
+    p.write_text('[world]\ngrid = [\n    "XXX",\n    "X X",  # hole\n    "XX",\n]\n')
+    g = WorldGrid.from_toml(str(p))
+    assert g.rows() == ["XXX", "X X", "XX "]
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (3, 1), (5, 2), (6, 3), (7, 6), (8, 4)])
+def test_totalizer_is_exactly_at_most_k(n, k):
+    """Brute force: an input assignment extends to a model of the encoding iff at most k inputs are true."""
+    from oracle import oracle as ora
+    grid = WorldGrid.rect(n, 1)
+    enc = Encoding.encode([(1, 1)], grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+    inputs = [enc.platform_var(x, 0, (1, 1)) for x in range(n)]
+    base = enc.base_cnf().n_clauses
+    card = cnf.clauses()[base:]
+    for bits in itertools.product([0, 1], repeat=n):
+        s = ora.OracleSolver()
+        lits, offs = ora.to_csr(card + [[v if b else -v] for v, b in zip(inputs, bits)])
+        s.reserve(cnf.n_vars)
+        s.add_cnf(lits, offs)
+        assert (s.solve() == 10) == (sum(bits) <= k)
+
+
+def test_sweep_outputs_pose_tighter_bounds_as_assumptions():
+    from oracle import oracle as ora
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode([(1, 1)], grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 8}), sweep=True)
+    assert len(cnf.card_outputs) == 9
+    for k, want in [(3, 20), (4, 10), (8, 10)]:
+        s = ora.OracleSolver()
+        s.add_cnf(cnf.lits, cnf.offsets)
+        assert s.solve([-int(cnf.card_outputs[k])] if k < 8 else []) == want

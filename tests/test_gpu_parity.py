@@ -1,0 +1,174 @@
+"""GPU parity tests (run on a real MI355X with -m gpu).  Everything goes through the C ABI of
+libmi355sat.so; the oracle (CPU) is the checker.  Bars: verdicts equal the golden / oracle verdicts;
+every SAT model satisfies every clause, yields a layout that validates and has <= k platforms; BCP
+fixpoints are bit-exact."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from helpers import VERDICTS, check_sat_answer, make_grid, platform_defs, scripted_decisions
+from oracle import oracle as ora
+from timberborn_support_solver_amd import (Encoding, Mi355Sat, PlatformLayout, PlatformLimits, SolverResult,
+                                           algorithmic_bytes, solver_loop)
+
+pytestmark = pytest.mark.gpu
+
+LADDER = [v for v in VERDICTS["verdicts"] if v["picosat_seconds"] < 1.0]
+
+
+@pytest.mark.parametrize("v", LADDER, ids=lambda v: f"{v['terrain']}-{v['platforms']}-k{v['k']}")
+def test_golden_verdicts(v):
+    grid = make_grid(v["terrain"])
+    enc = Encoding.encode(platform_defs(v["platforms"]), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): v["k"]}))
+    s = Mi355Sat(workers=64)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    r = s.solve()
+    assert r.name.upper() == v["verdict"]
+    if r == SolverResult.Sat:
+        check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, v["k"])
+    st = s.stats()
+    assert st["propagations"] == st["n_deq"] and st["n_clauses"] == cnf.n_clauses and st["max_var"] == cnf.n_vars
+    s.close()
+
+
+@pytest.mark.parametrize("terrain,pset,k,n_dec", [("rect16x16", "default", 40, 12), ("ex3", "default", 20, 8),
+                                                  ("rect16x16", "1x1", 40, 30), ("rect32x32", "default", 120, 16)])
+def test_bcp_fixpoints_bit_exact(terrain, pset, k, n_dec):
+    """BASELINE.json configs[1]: single-instance BCP from the formula's unit clauses and from scripted
+    decision sequences (splitmix64 seeds 1..16), compared literal-for-literal with the oracle."""
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+    scripts = [[]] + [scripted_decisions(enc, grid, seed, n_dec, p_positive=0.15) for seed in range(1, 17)]
+    s = Mi355Sat()
+    s.add_cnf(cnf.lits, cnf.offsets)
+    confl, vals, tl = s.propagate_batch(scripts, n_vars=cnf.n_vars)
+    n_fix = 0
+    for i, dec in enumerate(scripts):
+        c, v, n, _ = ora.bcp(cnf.lits, cnf.offsets, cnf.n_vars, dec)
+        assert c == confl[i], (i, dec)
+        if not c:
+            n_fix += 1
+            assert n == tl[i] and np.array_equal(v, vals[i]), i
+    assert n_fix >= 4
+    # idempotence: propagating a fixpoint's own literals changes nothing
+    i = int(np.argmin(confl))
+    fix = [int(v + 1) * int(vals[i][v]) for v in range(cnf.n_vars) if vals[i][v] != 0][:200]
+    c2, v2, t2 = s.propagate_batch([scripts[i] + fix], n_vars=cnf.n_vars)
+    assert c2[0] == 0 and np.array_equal(v2[0], vals[i])
+    s.close()
+
+
+def test_sweep_shares_one_clause_database():
+    grid = make_grid("rect16x16")
+    enc = Encoding.encode(platform_defs("default"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 12}), sweep=True)
+    ks = [12, 8, 5, 4, 3, 2]
+    s = Mi355Sat(workers=96)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    res = s.solve_batch([[-int(cnf.card_outputs[k])] if k < 12 else [] for k in ks])
+    assert [r.name for r in res] == ["Sat", "Sat", "Sat", "Sat", "Unsat", "Unsat"]      # k* = 4 (golden)
+    for i, k in enumerate(ks):
+        if res[i] == SolverResult.Sat:
+            check_sat_answer(cnf, s.solution_of(i, cnf.n_vars), enc, grid, k)
+    s.close()
+
+
+@pytest.mark.parametrize("terrain,pset,k0,kstar", [("rect8x8", "default", 20, 2), ("ex3", "default", 20, 1),
+                                                   ("ex3", "1x1", 20, 4), ("ex1", "default", 20, 1),
+                                                   ("rect16x16", "default", 40, 4)])
+def test_solver_loop_reaches_the_known_optimum(terrain, pset, k0, kstar):
+    """configs[0] (through the GPU instead of the CPU reference) and configs[3]: the decreasing-k loop."""
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    lines = []
+    hist = solver_loop(grid, enc, PlatformLimits({(1, 1): k0}), make_solver=lambda: Mi355Sat(workers=64), out=lines.append)
+    assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == kstar - 1
+    assert all(h["result"] == SolverResult.Sat and h["valid"] and h["count"] <= h["k"] for h in hist[:-1])
+    assert hist[-2]["count"] == kstar
+    assert lines[-1] == "No solution found for the current constraints"
+
+
+def test_rect32_full_cdcl_harder_rungs():
+    """configs[2] rungs that finish quickly: rect 32x32 default at k = 120 and 24 (SAT), and the
+    refutation of k = 10 (optimum is 15 per SURVEY §6), cross-checked with the oracle."""
+    grid = make_grid("rect32x32")
+    enc = Encoding.encode(platform_defs("default"), grid)
+    for k, want in [(120, SolverResult.Sat), (24, SolverResult.Sat), (10, SolverResult.Unsat)]:
+        cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+        s = Mi355Sat(workers=256)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        r = s.solve()
+        assert r == want, k
+        if r == SolverResult.Sat:
+            check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+        else:
+            o = ora.OracleSolver()
+            o.add_cnf(cnf.lits, cnf.offsets)
+            assert o.solve() == 20
+        s.close()
+
+
+def test_full_size_64x64_properties():
+    """At BASELINE's full size the oracle is too slow to re-solve, so check size-independent
+    properties: SAT models self-certify; BCP fixpoints equal the oracle's (BCP is cheap); counters add up."""
+    grid = make_grid("rect64x64")
+    enc = Encoding.encode(platform_defs("default"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 200}))
+    s = Mi355Sat(workers=256)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    assert s.solve() == SolverResult.Sat                       # loose bound: "trivial to find" (README.md:23)
+    lay = check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, 200)
+    assert lay.platform_count() >= 43                          # area bound ceil(4096/97)
+    st = s.stats()
+    assert algorithmic_bytes(st) > 0 and st["kernel_seconds"] > 0
+    s.close()
+    scripts = [[]] + [scripted_decisions(enc, grid, seed, 24, p_positive=0.1) for seed in range(1, 8)]
+    s = Mi355Sat()
+    s.add_cnf(cnf.lits, cnf.offsets)
+    confl, vals, tl = s.propagate_batch(scripts, n_vars=cnf.n_vars)
+    for i, dec in enumerate(scripts):
+        c, v, n, _ = ora.bcp(cnf.lits, cnf.offsets, cnf.n_vars, dec)
+        assert c == confl[i]
+        if not c:
+            assert n == tl[i] and np.array_equal(v, vals[i])
+    s.close()
+
+
+def test_interrupt_and_budget():
+    grid = make_grid("rect16x16")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 13}))   # hard refutation
+    s = Mi355Sat(workers=64, slice_conflicts=500)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    intr = s.interrupter()
+    threading.Timer(1.0, intr.interrupt).start()
+    t0 = time.time()
+    r = s.solve()
+    assert r in (SolverResult.Interrupted, SolverResult.Unsat) and time.time() - t0 < 120
+    if r == SolverResult.Interrupted:
+        assert s.stats()["n_terminated"] == 1
+    s.close()
+    s = Mi355Sat(workers=64, slice_conflicts=100, conflict_budget=3000)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    assert s.solve() == SolverResult.Interrupted
+    s.close()
+
+
+def test_degenerate_inputs_on_device():
+    s = Mi355Sat()
+    assert s.solve() == SolverResult.Sat
+    s.close()
+    s = Mi355Sat()
+    s.add_clause([1, 2]); s.add_clause([-1, 2]); s.add_clause([1, -2]); s.add_clause([-1, -2])
+    assert s.solve() == SolverResult.Unsat                     # needs one device conflict at level 0
+    s.close()
+    s = Mi355Sat()
+    s.add_clause([1, 2, 3]); s.add_clause([-1, -2]); s.add_clause([-3]); s.reserve(7)
+    assert s.solve() == SolverResult.Sat
+    m = s.full_solution(7)
+    assert m[2] == -1 and (m[0] == 1) != (m[1] == 1) or (m[0] == 1 and m[1] == -1) or (m[0] == -1 and m[1] == 1)
+    s.close()

@@ -1,0 +1,118 @@
+// layout.h — data layout in HBM shared by the host driver and the HIP kernels.
+//
+// One *worker* = one 64-lane wavefront running a complete CDCL search (or a
+// scripted BCP) on its own copy of the mutable solver state.  Everything a
+// worker mutates lives in ONE contiguous slab of HBM (`slab_bytes` per
+// worker); everything immutable (clause literals, clause offsets, the binary
+// implication CSR) exists once per GPU and is read by all workers, so it is
+// served from L2 / Infinity Cache while the private slabs stream from HBM.
+//
+// Literal encoding on the device: lit = 2*var + neg, var 0-based.
+#pragma once
+#include <stdint.h>
+
+#define MS_WAVE 64
+#define MS_LDS_RING 1024          // per-wave propagation queue window in LDS (entries)
+#define MS_CLAIM_SLOTS 256        // per-wave implication claim table in LDS
+#define MS_OVERFLOW_CAP 192       // watcher pushes that found their list full, per chunk
+#define MS_LBDQ 50                // Glucose restart window
+#define MS_VAL_TRUE 0
+#define MS_VAL_FALSE 1
+#define MS_VAL_UNDEF 2
+
+#define MS_REASON_NONE (-1)
+// binary reason: the clause (x | other) implied x; stored as -2 - other
+#define MS_REASON_BIN(other) (-2 - (other))
+#define MS_IS_BIN_REASON(r) ((r) <= -2)
+#define MS_BIN_REASON_LIT(r) (-2 - (r))
+
+enum {
+    MS_ST_RUNNING = 0,
+    MS_ST_SAT = 10,
+    MS_ST_UNSAT = 20,          // formula (with this worker's assumptions) refuted
+    MS_ST_PARKED = 120,        // another worker already decided this instance
+    MS_ST_ERR_POOL = -1,       // watch pool exhausted
+    MS_ST_ERR_LEARNT = -2,     // learnt clause store exhausted
+    MS_ST_ERR_INTERNAL = -3,
+};
+
+// Immutable, one per GPU.
+struct MsShared {
+    uint32_t n_vars;
+    uint32_t n_orig;               // long (>=3 literal) original clauses, cref 0..n_orig-1
+    const uint32_t* cl_off;        // n_orig+1 offsets into cl_lits
+    const int32_t* cl_lits;        // literals of the long original clauses
+    const uint32_t* bin_off;       // 2*n_vars+1: implications of literal p being TRUE
+    const int32_t* bin_lits;       // implied literals q  (clause  ~p | q)
+};
+
+// Byte offsets of the private arrays inside a worker slab.
+struct MsLayout {
+    uint64_t slab_bytes;
+    uint64_t state;       // MsState
+    uint64_t val;         // uint8  [n_vars]   MS_VAL_*
+    uint64_t phase;       // uint8  [n_vars]   saved sign (1 = assign false)
+    uint64_t seen;        // uint8  [n_vars]
+    uint64_t level;       // int32  [n_vars]
+    uint64_t reason;      // int32  [n_vars]
+    uint64_t trail;       // int32  [n_vars]
+    uint64_t trail_lim;   // int32  [n_vars+1]
+    uint64_t vm_pos;      // int32  [n_vars]   index of the var's live entry in vm_order
+    uint64_t vm_order;    // int32  [vm_cap]   move-to-front queue as an append-only array
+    uint64_t wl;          // int2   [n_orig + learnt_cap]  the two watched literals per clause
+    uint64_t w_base;      // uint32 [2*n_vars] start of the literal's watch list in pool
+    uint64_t w_size;      // uint32 [2*n_vars]
+    uint64_t w_cap;       // uint32 [2*n_vars]
+    uint64_t pool;        // int2   [pool_cap]  watcher = (cref, blocker)
+    uint64_t lc_off;      // uint32 [learnt_cap+1]
+    uint64_t lc_lbd;      // uint32 [learnt_cap]  lbd | used<<31
+    uint64_t lc_lits;     // int32  [learnt_lit_cap]
+    uint64_t learnt_buf;  // int32  [n_vars+1]   clause under construction
+    uint64_t toclear;     // int32  [n_vars+1]   vars touched by analysis
+    uint64_t lvl_stamp;   // uint32 [n_vars+2]   LBD computation
+    uint64_t remap;       // uint32 [learnt_cap] reduceDB old->new
+    uint64_t overflow;    // int32  [3*MS_OVERFLOW_CAP]  (list, cref, blocker)
+    uint64_t assumps;     // int32  [assump_cap]
+    uint64_t script;      // int32  [script_cap]  decisions for propagate_batch
+    uint32_t n_vars, n_orig, learnt_cap, learnt_lit_cap, pool_cap, vm_cap, assump_cap, script_cap;
+};
+
+// Per-worker scalar state (lives at slab + layout.state); 8-byte aligned.
+struct MsState {
+    int32_t status;            // MS_ST_*
+    int32_t trail_n, qhead, n_levels;
+    int32_t n_assumps;
+    int32_t n_script;
+    int32_t conflict_kind;     // scratch
+    int32_t pad0;
+    // decision queue
+    int32_t vm_end, vm_search;
+    // learnt store
+    uint32_t n_learnts, lc_lits_n, pool_top, pad1;
+    // restarts (Glucose K=0.8 on LBD window, R=1.4 trail blocking)
+    uint32_t lbdq[MS_LBDQ];
+    uint32_t lbdq_n, lbdq_i;
+    uint64_t lbdq_sum, lbd_total;
+    double trail_avg;          // exponential moving average stands in for Glucose's 5000-entry queue
+    uint64_t next_reduce;
+    uint32_t lvl_stamp_ctr, pad2;
+    uint64_t rng;
+    // counters
+    uint64_t propagations, decisions, conflicts, restarts, reduce_dbs;
+    uint64_t n_watch, n_cl_lit, n_move, n_enq;
+    uint64_t learnt_total, learnt_lits_total;
+    uint64_t slice_cycles;
+    uint64_t reserved[8];
+};
+
+// Launch parameters of one slice.
+struct MsParams {
+    uint32_t n_workers;
+    uint32_t slice_conflicts;      // stop the slice after this many conflicts per worker
+    uint64_t slice_props;          // ... or this many propagations (0 = unlimited)
+    const volatile int32_t* stop_flag;  // pinned host int: nonzero -> leave the slice early
+    int32_t stop_on_any;           // device-side flag ptr below is set by the first finished worker
+    int32_t mode;                  // 0 = CDCL search, 1 = scripted BCP
+    int32_t* any_done;             // device int, set when a worker reaches SAT/UNSAT
+    uint32_t reduce_first, reduce_inc;
+};

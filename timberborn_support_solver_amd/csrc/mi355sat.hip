@@ -1,0 +1,979 @@
+// mi355sat.hip — libmi355sat.so: the C ABI of include/mi355sat.h over the HIP
+// kernels in device/kernels.hip.h.  Host duties only: clause intake and
+// normalisation, building the immutable clause database and the per-worker slab
+// template, replicating it into HBM, launching slices of the search kernel, and
+// reading verdicts / models / counters back.  There is no CPU solving path: if
+// HIP is unavailable every entry point fails.
+//
+// Reference call sites this file serves (see include/mi355sat.h for the mapping):
+//   crates/repl/src/solver_runner.rs:12-16, crates/repl/src/main.rs:295,316,329,363,
+//   crates/gui/src/solver_backend.rs:78-90.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355sat.h"
+#include "device/kernels.hip.h"
+
+namespace {
+
+std::string g_new_error;
+std::mutex g_new_error_mu;
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct HipErr { std::string msg; };
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess)                                                                       \
+            throw HipErr{std::string(#x) + ": " + hipGetErrorString(e_)};                            \
+    } while (0)
+
+// ---- auxiliary kernels ---------------------------------------------------------
+// Per-worker customisation after the template slab has been replicated:
+// assumptions, scripted decisions and a worker-specific initial decision order
+// (affine permutation of the variables; worker group 0 keeps the canonical order).
+__global__ void ms_customize_kernel(MsLayout L, char* slabs, uint32_t n_workers, const int32_t* assump_data,
+                                    const uint64_t* assump_off, const int32_t* script_data,
+                                    const uint64_t* script_off, uint32_t n_instances, uint64_t seed) {
+    const uint32_t wid = blockIdx.x;
+    if (wid >= n_workers) return;
+    char* slab = slabs + (size_t)wid * L.slab_bytes;
+    MsState* st = (MsState*)(slab + L.state);
+    const uint32_t inst = n_instances ? wid % n_instances : 0;
+    const uint32_t replica = n_instances ? wid / n_instances : wid;
+    if (assump_off) {
+        uint64_t a0 = assump_off[inst], a1 = assump_off[inst + 1];
+        int32_t* dst = (int32_t*)(slab + L.assumps);
+        for (uint64_t i = threadIdx.x; i < a1 - a0; i += blockDim.x) dst[i] = assump_data[a0 + i];
+        if (threadIdx.x == 0) st->n_assumps = (int32_t)(a1 - a0);
+    }
+    if (script_off) {
+        uint64_t a0 = script_off[inst], a1 = script_off[inst + 1];
+        int32_t* dst = (int32_t*)(slab + L.script);
+        for (uint64_t i = threadIdx.x; i < a1 - a0; i += blockDim.x) dst[i] = script_data[a0 + i];
+        if (threadIdx.x == 0) st->n_script = (int32_t)(a1 - a0);
+    }
+    if (threadIdx.x == 0) st->rng = seed * 0x9E3779B97F4A7C15ull + wid;
+    if (replica > 0 && L.n_vars > 2) {
+        // splitmix64 -> multiplier coprime to n_vars, offset
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(replica + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const uint32_t n = L.n_vars;
+        uint32_t a = (uint32_t)(z % n) | 1u, b = (uint32_t)((z >> 32) % n);
+        for (;;) {
+            uint32_t x = a, y = n;
+            while (y) { uint32_t t = x % y; x = y; y = t; }
+            if (x == 1) break;
+            a += 2;
+            if (a >= n) a = 1;
+        }
+        int32_t* order = (int32_t*)(slab + L.vm_order);
+        int32_t* pos = (int32_t*)(slab + L.vm_pos);
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            uint32_t v = (uint32_t)(((uint64_t)a * i + b) % n);
+            order[i] = (int32_t)v;
+            pos[v] = (int32_t)i;
+        }
+    }
+}
+
+__global__ void ms_gather_states_kernel(MsLayout L, const char* slabs, uint32_t n_workers, MsState* out) {
+    const uint32_t wid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wid >= n_workers) return;
+    out[wid] = *(const MsState*)(slabs + (size_t)wid * L.slab_bytes + L.state);
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    void upload(const std::vector<T>& v, hipStream_t s) {
+        alloc(v.size());
+        if (!v.empty()) HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+struct mi355sat {
+    mi355sat_opts opts{};
+    int device = 0;
+    // clause intake (DIMACS literals)
+    std::vector<int32_t> lits;
+    std::vector<uint64_t> offs{0};
+    std::vector<int32_t> pending;
+    uint64_t max_var = 0;
+    // results
+    std::vector<int8_t> model;                 // plain solve
+    std::vector<std::vector<int8_t>> batch_models;
+    mi355sat_stats_t stats{};
+    std::string err;
+    std::string proof_path;
+    // interrupt flag: pinned host memory the kernels poll
+    int32_t* stop_flag = nullptr;
+    std::atomic<int> interrupted{0};
+    // device
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf<uint32_t> d_cl_off, d_bin_off;
+    DevBuf<int32_t> d_cl_lits, d_bin_lits;
+    DevBuf<char> d_template, d_slabs;
+    DevBuf<MsState> d_states;
+    DevBuf<int32_t> d_any_done, d_assump, d_script;
+    DevBuf<uint64_t> d_assump_off, d_script_off;
+    MsShared sh{};
+    MsLayout L{};
+    uint32_t n_workers = 0;
+    // prepared formula facts
+    bool trivially_unsat = false;
+    std::vector<int8_t> fixed;                 // per var: 0 free, 1 true, -1 false (level-0 facts)
+    uint32_t n_vars = 0;
+    struct SweepHolder* sweep = nullptr;        // stepwise sweep in progress (mi355sat_sweep_*)
+};
+
+namespace {
+
+// ---- formula preparation ---------------------------------------------------------
+struct Prepared {
+    uint32_t n_vars = 0;
+    bool unsat = false;
+    std::vector<int32_t> units;                 // internal literals fixed at level 0 (trail prefix)
+    bool units_propagated = false;              // true if simplification ran (queue starts empty)
+    std::vector<uint32_t> cl_off{0};
+    std::vector<int32_t> cl_lits;
+    std::vector<uint32_t> bin_off;
+    std::vector<int32_t> bin_lits;
+};
+
+inline int32_t to_internal(int32_t d) { return d > 0 ? 2 * (d - 1) : 2 * (-d - 1) + 1; }
+
+void prepare(const mi355sat& s, bool simplify, Prepared& P) {
+    const uint32_t nv = (uint32_t)s.max_var;
+    P.n_vars = nv;
+    const size_t nc = s.offs.size() - 1;
+    std::vector<int8_t> val(nv, 0);  // 0 unassigned, 1 true, -1 false
+    // normalised clauses
+    std::vector<int32_t> nl;
+    std::vector<uint64_t> no{0};
+    nl.reserve(s.lits.size());
+    std::vector<int32_t> tmp;
+    auto assign_unit = [&](int32_t l) -> bool {  // false on contradiction
+        int8_t want = (l & 1) ? -1 : 1;
+        int8_t& v = val[l >> 1];
+        if (v == 0) { v = want; P.units.push_back(l); return true; }
+        return v == want;
+    };
+    for (size_t c = 0; c < nc && !P.unsat; c++) {
+        tmp.clear();
+        for (uint64_t k = s.offs[c]; k < s.offs[c + 1]; k++) tmp.push_back(to_internal(s.lits[k]));
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        bool taut = false;
+        for (size_t i = 0; i + 1 < tmp.size(); i++) taut = taut || (tmp[i] ^ 1) == tmp[i + 1];
+        if (taut) continue;
+        if (tmp.empty()) { P.unsat = true; break; }
+        if (tmp.size() == 1) { if (!assign_unit(tmp[0])) P.unsat = true; continue; }
+        nl.insert(nl.end(), tmp.begin(), tmp.end());
+        no.push_back(nl.size());
+    }
+    if (P.unsat) return;
+    size_t nn = no.size() - 1;
+    if (simplify) {
+        // level-0 unit propagation over occurrence lists, then strip
+        std::vector<uint32_t> occ_off(2 * (size_t)nv + 1, 0);
+        for (int32_t l : nl) occ_off[l + 1]++;
+        for (size_t i = 0; i < 2 * (size_t)nv; i++) occ_off[i + 1] += occ_off[i];
+        std::vector<uint32_t> occ(nl.size()), fill(occ_off.begin(), occ_off.end() - 1);
+        for (size_t c = 0; c < nn; c++)
+            for (uint64_t k = no[c]; k < no[c + 1]; k++) occ[fill[nl[k]]++] = (uint32_t)c;
+        auto lv = [&](int32_t l) { int8_t v = val[l >> 1]; return (l & 1) ? (int8_t)-v : v; };
+        size_t qh = 0;
+        while (qh < P.units.size() && !P.unsat) {
+            int32_t p = P.units[qh++];
+            int32_t f = p ^ 1;
+            for (uint32_t e = occ_off[f]; e < occ_off[f + 1] && !P.unsat; e++) {
+                uint32_t c = occ[e];
+                int32_t unit = -1;
+                int nfree = 0;
+                bool sat = false;
+                for (uint64_t k = no[c]; k < no[c + 1]; k++) {
+                    int8_t v = lv(nl[k]);
+                    if (v > 0) { sat = true; break; }
+                    if (v == 0) { nfree++; unit = nl[k]; }
+                }
+                if (sat) continue;
+                if (nfree == 0) P.unsat = true;
+                else if (nfree == 1 && !assign_unit(unit)) P.unsat = true;
+            }
+        }
+        if (P.unsat) return;
+        P.units_propagated = true;
+        std::vector<int32_t> nl2;
+        std::vector<uint64_t> no2{0};
+        nl2.reserve(nl.size());
+        for (size_t c = 0; c < nn; c++) {
+            bool sat = false;
+            size_t start = nl2.size();
+            for (uint64_t k = no[c]; k < no[c + 1]; k++) {
+                int8_t v = lv(nl[k]);
+                if (v > 0) { sat = true; break; }
+                if (v == 0) nl2.push_back(nl[k]);
+            }
+            if (sat) { nl2.resize(start); continue; }
+            no2.push_back(nl2.size());
+        }
+        nl.swap(nl2);
+        no.swap(no2);
+        nn = no.size() - 1;
+    }
+    // split binary / long
+    std::vector<std::pair<int32_t, int32_t>> bins;
+    for (size_t c = 0; c < nn; c++) {
+        uint64_t len = no[c + 1] - no[c];
+        if (len == 2) bins.push_back({nl[no[c]], nl[no[c] + 1]});
+        else {
+            P.cl_lits.insert(P.cl_lits.end(), nl.begin() + no[c], nl.begin() + no[c + 1]);
+            P.cl_off.push_back((uint32_t)P.cl_lits.size());
+        }
+    }
+    std::sort(bins.begin(), bins.end());
+    bins.erase(std::unique(bins.begin(), bins.end()), bins.end());
+    P.bin_off.assign(2 * (size_t)nv + 1, 0);
+    for (auto& b : bins) { P.bin_off[(b.first ^ 1) + 1]++; P.bin_off[(b.second ^ 1) + 1]++; }
+    for (size_t i = 0; i < 2 * (size_t)nv; i++) P.bin_off[i + 1] += P.bin_off[i];
+    P.bin_lits.resize(2 * bins.size());
+    std::vector<uint32_t> fill(P.bin_off.begin(), P.bin_off.end() - 1);
+    for (auto& b : bins) {
+        P.bin_lits[fill[b.first ^ 1]++] = b.second;   // ~a -> b
+        P.bin_lits[fill[b.second ^ 1]++] = b.first;   // ~b -> a
+    }
+}
+
+// ---- slab template -----------------------------------------------------------------
+void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_t script_cap,
+                               std::vector<char>& tmpl) {
+    const uint32_t nv = P.n_vars, no = (uint32_t)P.cl_off.size() - 1;
+    MsLayout& L = s.L;
+    memset(&L, 0, sizeof L);
+    L.n_vars = nv;
+    L.n_orig = no;
+    // capacities
+    const uint64_t base_lits = P.cl_lits.size();
+    L.learnt_cap = (uint32_t)std::min<uint64_t>(1u << 17, std::max<uint64_t>(1u << 14, 2 * (uint64_t)no + 4096));
+    L.learnt_lit_cap = (uint32_t)std::min<uint64_t>(6u << 20, std::max<uint64_t>(1u << 19, 4 * base_lits));
+    L.vm_cap = 3 * nv + 256;
+    L.assump_cap = assump_cap;
+    L.script_cap = script_cap;
+    // watch capacities: list of literal t holds clauses watching ~t: at most occ(~t) originals
+    std::vector<uint32_t> cap(2 * (size_t)nv, 0);
+    for (int32_t l : P.cl_lits) cap[l ^ 1]++;
+    uint64_t pool_need = 0;
+    std::vector<uint32_t> base(2 * (size_t)nv);
+    for (size_t t = 0; t < cap.size(); t++) {
+        cap[t] += 4;
+        base[t] = (uint32_t)pool_need;
+        pool_need += cap[t];
+    }
+    uint64_t pool_cap = pool_need + std::max<uint64_t>(pool_need / 2, 1u << 18);
+    if (pool_cap > 0xfffffff0ull) throw HipErr{"formula too large (watch pool)"};
+    L.pool_cap = (uint32_t)pool_cap;
+    size_t off = 0;
+    auto place = [&](uint64_t& field, size_t bytes) { field = off; off = align_up(off + bytes, 256); };
+    place(L.state, sizeof(MsState));
+    place(L.val, nv);
+    place(L.phase, nv);
+    place(L.seen, nv);
+    place(L.level, 4 * (size_t)nv);
+    place(L.reason, 4 * (size_t)nv);
+    place(L.trail, 4 * (size_t)nv);
+    place(L.trail_lim, 4 * ((size_t)nv + 1));
+    place(L.vm_pos, 4 * (size_t)nv);
+    place(L.vm_order, 4 * (size_t)L.vm_cap);
+    place(L.wl, 8 * ((size_t)no + L.learnt_cap));
+    place(L.w_base, 4 * 2 * (size_t)nv);
+    place(L.w_size, 4 * 2 * (size_t)nv);
+    place(L.w_cap, 4 * 2 * (size_t)nv);
+    place(L.lc_off, 4 * ((size_t)L.learnt_cap + 1));
+    place(L.lc_lbd, 4 * (size_t)L.learnt_cap);
+    place(L.learnt_buf, 4 * ((size_t)nv + 1));
+    place(L.toclear, 4 * ((size_t)nv + 1));
+    place(L.lvl_stamp, 4 * ((size_t)nv + 2));
+    place(L.remap, 4 * (size_t)L.learnt_cap);
+    place(L.overflow, 4 * 3 * MS_OVERFLOW_CAP);
+    place(L.assumps, 4 * (size_t)std::max<uint32_t>(assump_cap, 1));
+    place(L.script, 4 * (size_t)std::max<uint32_t>(script_cap, 1));
+    // the big, cold-tailed arrays last
+    place(L.lc_lits, 4 * (size_t)L.learnt_lit_cap);
+    place(L.pool, 8 * (size_t)L.pool_cap);
+    L.slab_bytes = align_up(off, 4096);
+
+    // Only the head of the slab (everything before lc_lits) plus the initial watch
+    // pool needs initial contents; lc_lits is left as allocated.
+    tmpl.assign(L.slab_bytes, 0);
+    char* T = tmpl.data();
+    MsState* st = (MsState*)(T + L.state);
+    st->status = MS_ST_RUNNING;
+    st->trail_n = (int32_t)P.units.size();
+    st->qhead = P.units_propagated ? st->trail_n : 0;
+    st->n_levels = 0;
+    st->vm_end = (int32_t)nv;
+    st->vm_search = (int32_t)nv - 1;
+    st->pool_top = (uint32_t)pool_need;
+    st->next_reduce = s.opts.reduce_first > 0 ? (uint64_t)s.opts.reduce_first : 2000;
+    memset(T + L.val, MS_VAL_UNDEF, nv);
+    memset(T + L.phase, 1, nv);
+    int32_t* reason = (int32_t*)(T + L.reason);
+    for (uint32_t v = 0; v < nv; v++) reason[v] = MS_REASON_NONE;
+    int32_t* trail = (int32_t*)(T + L.trail);
+    for (size_t i = 0; i < P.units.size(); i++) {
+        int32_t l = P.units[i];
+        trail[i] = l;
+        ((uint8_t*)(T + L.val))[l >> 1] = (uint8_t)(l & 1);
+    }
+    int32_t* vm_pos = (int32_t*)(T + L.vm_pos);
+    int32_t* vm_order = (int32_t*)(T + L.vm_order);
+    for (uint32_t v = 0; v < nv; v++) { vm_order[nv - 1 - v] = (int32_t)v; vm_pos[v] = (int32_t)(nv - 1 - v); }
+    int2* wl = (int2*)(T + L.wl);
+    uint32_t* w_base = (uint32_t*)(T + L.w_base);
+    uint32_t* w_size = (uint32_t*)(T + L.w_size);
+    uint32_t* w_cap = (uint32_t*)(T + L.w_cap);
+    int2* pool = (int2*)(T + L.pool);
+    for (size_t t = 0; t < cap.size(); t++) { w_base[t] = base[t]; w_cap[t] = cap[t]; w_size[t] = 0; }
+    for (uint32_t c = 0; c < no; c++) {
+        int32_t a = P.cl_lits[P.cl_off[c]], b = P.cl_lits[P.cl_off[c] + 1];
+        wl[c] = make_int2(a, b);
+        pool[w_base[a ^ 1] + w_size[a ^ 1]++] = make_int2((int)c, b);
+        pool[w_base[b ^ 1] + w_size[b ^ 1]++] = make_int2((int)c, a);
+    }
+}
+
+void set_error(mi355sat* s, const std::string& m) { s->err = m; }
+
+void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_t script_cap, uint32_t want_workers) {
+    HIPCHK(hipSetDevice(s.device));
+    std::vector<char> tmpl;
+    build_layout_and_template(s, P, assump_cap, script_cap, tmpl);
+    s.n_vars = P.n_vars;
+    s.d_cl_off.upload(P.cl_off, s.stream);
+    s.d_cl_lits.upload(P.cl_lits, s.stream);
+    s.d_bin_off.upload(P.bin_off, s.stream);
+    s.d_bin_lits.upload(P.bin_lits, s.stream);
+    s.sh.n_vars = P.n_vars;
+    s.sh.n_orig = (uint32_t)P.cl_off.size() - 1;
+    s.sh.cl_off = s.d_cl_off.p;
+    s.sh.cl_lits = s.d_cl_lits.p;
+    s.sh.bin_off = s.d_bin_off.p;
+    s.sh.bin_lits = s.d_bin_lits.p;
+    // worker count limited by free HBM
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    uint64_t fit = (uint64_t)((double)free_b * 0.85) / (s.L.slab_bytes * 1ull);
+    if (fit < 2) throw HipErr{"not enough device memory for one worker slab"};
+    uint32_t W = (uint32_t)std::min<uint64_t>(want_workers, fit - 1);
+    if (W == 0) W = 1;
+    s.n_workers = W;
+    s.d_template.alloc(s.L.slab_bytes);
+    HIPCHK(hipMemcpyAsync(s.d_template.p, tmpl.data(), s.L.slab_bytes, hipMemcpyHostToDevice, s.stream));
+    s.d_slabs.alloc((size_t)W * s.L.slab_bytes);
+    s.d_states.alloc(W);
+    s.d_any_done.alloc(1);
+    HIPCHK(hipStreamSynchronize(s.stream));
+    if (s.opts.verbose)
+        fprintf(stderr, "[mi355sat] vars=%u long=%u bin=%zu units=%zu slab=%.2f MiB workers=%u\n", P.n_vars,
+                s.sh.n_orig, P.bin_lits.size() / 2, P.units.size(), s.L.slab_bytes / 1048576.0, W);
+}
+
+// Replicate the template into every worker slab (head + initial watch pool only).
+void reset_workers(mi355sat& s) {
+    const MsLayout& L = s.L;
+    const size_t head = L.lc_lits;  // everything before the learnt literal store
+    const MsState* tst = nullptr;
+    (void)tst;
+    for (uint32_t w = 0; w < s.n_workers; w++) {
+        char* dst = s.d_slabs.p + (size_t)w * L.slab_bytes;
+        HIPCHK(hipMemcpyAsync(dst, s.d_template.p, head, hipMemcpyDeviceToDevice, s.stream));
+        HIPCHK(hipMemcpyAsync(dst + L.pool, s.d_template.p + L.pool, 8 * (size_t)L.pool_cap,
+                              hipMemcpyDeviceToDevice, s.stream));
+    }
+    HIPCHK(hipMemsetAsync(s.d_any_done.p, 0, sizeof(int32_t), s.stream));
+}
+
+void customize(mi355sat& s, const std::vector<int32_t>* assump, const std::vector<uint64_t>* assump_off,
+               const std::vector<int32_t>* script, const std::vector<uint64_t>* script_off, uint32_t n_instances) {
+    if (assump_off) {
+        s.d_assump.upload(assump->empty() ? std::vector<int32_t>{0} : *assump, s.stream);
+        s.d_assump_off.upload(*assump_off, s.stream);
+    }
+    if (script_off) {
+        s.d_script.upload(script->empty() ? std::vector<int32_t>{0} : *script, s.stream);
+        s.d_script_off.upload(*script_off, s.stream);
+    }
+    hipLaunchKernelGGL(ms_customize_kernel, dim3(s.n_workers), dim3(256), 0, s.stream, s.L, s.d_slabs.p,
+                       s.n_workers, assump_off ? s.d_assump.p : nullptr, assump_off ? s.d_assump_off.p : nullptr,
+                       script_off ? s.d_script.p : nullptr, script_off ? s.d_script_off.p : nullptr, n_instances,
+                       s.opts.seed);
+    HIPCHK(hipGetLastError());
+}
+
+void gather_states(mi355sat& s, std::vector<MsState>& out) {
+    out.resize(s.n_workers);
+    hipLaunchKernelGGL(ms_gather_states_kernel, dim3((s.n_workers + 63) / 64), dim3(64), 0, s.stream, s.L,
+                       s.d_slabs.p, s.n_workers, s.d_states.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out.data(), s.d_states.p, sizeof(MsState) * s.n_workers, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+}
+
+void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
+    mi355sat_stats_t& o = s.stats;
+    uint64_t learnts = 0, llits = 0;
+    uint64_t props = 0, dec = 0, confl = 0, rest = 0, red = 0, nw = 0, ncl = 0, nm = 0, ne = 0;
+    for (auto& st : sts) {
+        props += st.propagations; dec += st.decisions; confl += st.conflicts; rest += st.restarts;
+        red += st.reduce_dbs; nw += st.n_watch; ncl += st.n_cl_lit; nm += st.n_move; ne += st.n_enq;
+        learnts += st.n_learnts; llits += st.lc_lits_n;
+    }
+    o.propagations += props; o.decisions += dec; o.conflicts += confl; o.restarts += rest; o.reduce_dbs += red;
+    o.n_deq += props; o.n_watch += nw; o.n_cl_lit += ncl; o.n_move += nm; o.n_enq += ne;
+    o.learnts = learnts; o.learnt_literals = llits;
+}
+
+void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_t n_vars_out) {
+    std::vector<uint8_t> val(s.n_vars);
+    if (s.n_vars)
+        HIPCHK(hipMemcpy(val.data(), s.d_slabs.p + (size_t)worker * s.L.slab_bytes + s.L.val, s.n_vars,
+                         hipMemcpyDeviceToHost));
+    out.assign(n_vars_out, 0);
+    for (uint64_t v = 0; v < n_vars_out && v < s.n_vars; v++)
+        out[v] = val[v] == MS_VAL_TRUE ? 1 : (val[v] == MS_VAL_FALSE ? -1 : -1);  // free vars: false
+}
+
+struct SliceResult { float ms; };
+
+SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any) {
+    MsParams prm{};
+    prm.n_workers = s.n_workers;
+    prm.slice_conflicts = s.opts.slice_conflicts > 0 ? (uint32_t)s.opts.slice_conflicts : 2000u;
+    prm.slice_props = 0;
+    prm.stop_flag = s.stop_flag;
+    prm.stop_on_any = stop_on_any ? 1 : 0;
+    prm.mode = mode;
+    prm.any_done = s.d_any_done.p;
+    prm.reduce_first = s.opts.reduce_first > 0 ? (uint32_t)s.opts.reduce_first : 2000u;
+    prm.reduce_inc = s.opts.reduce_inc > 0 ? (uint32_t)s.opts.reduce_inc : 300u;
+    HIPCHK(hipEventRecord(s.ev0, s.stream));
+    if (mode == 0)
+        hipLaunchKernelGGL(ms_search_kernel, dim3(s.n_workers), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+    else
+        hipLaunchKernelGGL(ms_bcp_kernel, dim3(s.n_workers), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s.ev1, s.stream));
+    HIPCHK(hipEventSynchronize(s.ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
+    s.stats.kernel_seconds += ms * 1e-3;
+    s.stats.kernel_launches++;
+    return SliceResult{ms};
+}
+
+const char* status_text(int st) {
+    switch (st) {
+        case MS_ST_ERR_POOL: return "device watch pool exhausted";
+        case MS_ST_ERR_LEARNT: return "device learnt-clause store exhausted";
+        case MS_ST_ERR_INTERNAL: return "device solver internal error";
+        default: return "unknown device status";
+    }
+}
+
+// Shared driver for solve(), solve_batch() and the stepwise sweep API.
+// instance of worker w = w % n_instances.
+struct Sweep {
+    uint32_t n_instances = 0;
+    std::vector<int32_t> results, winner;
+    uint32_t decided = 0;
+    bool stop_at_first = false;
+    bool active = false;
+    std::vector<MsState> sts;
+    uint64_t conflicts = 0;
+};
+
+int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, const std::vector<uint64_t>& assump_off,
+                uint32_t n_instances, bool stop_at_first) {
+    Prepared P;
+    prepare(s, /*simplify=*/true, P);
+    sw = Sweep{};
+    sw.n_instances = n_instances;
+    sw.stop_at_first = stop_at_first;
+    sw.results.assign(n_instances, MI355SAT_INTERRUPTED);
+    sw.winner.assign(n_instances, -1);
+    if (P.unsat) {
+        std::fill(sw.results.begin(), sw.results.end(), MI355SAT_UNSAT);
+        sw.decided = n_instances;
+        s.trivially_unsat = true;
+        return 0;
+    }
+    uint32_t max_assumps = 0;
+    for (uint32_t i = 0; i < n_instances; i++)
+        max_assumps = std::max<uint32_t>(max_assumps, (uint32_t)(assump_off[i + 1] - assump_off[i]));
+    uint32_t want = s.opts.workers > 0 ? (uint32_t)s.opts.workers : 256u;
+    if (want < n_instances) want = n_instances;
+    want = want / n_instances * n_instances;
+    std::vector<int32_t> a_int(assump.size());
+    for (size_t i = 0; i < assump.size(); i++) {
+        int32_t d = assump[i];
+        if (d == 0 || (uint64_t)(d < 0 ? -(int64_t)d : d) > P.n_vars) throw HipErr{"assumption literal out of range"};
+        a_int[i] = to_internal(d);
+    }
+    upload_formula(s, P, max_assumps, 0, want);
+    if (s.n_workers < n_instances) throw HipErr{"not enough device memory for one worker per instance"};
+    s.n_workers = s.n_workers / n_instances * n_instances;
+    reset_workers(s);
+    customize(s, &a_int, &assump_off, nullptr, nullptr, n_instances);
+    HIPCHK(hipStreamSynchronize(s.stream));
+    sw.active = true;
+    return 0;
+}
+
+// One slice of the search kernel over all workers.  Returns 0 or a negative error.
+int sweep_step(mi355sat& s, Sweep& sw) {
+    if (!sw.active) return 0;
+    const uint32_t n_instances = sw.n_instances;
+    launch_slice(s, 0, /*stop_on_any=*/n_instances == 1 || sw.stop_at_first);
+    gather_states(s, sw.sts);
+    int rc = 0;
+    uint64_t confl = 0;
+    for (uint32_t w = 0; w < s.n_workers; w++) {
+        const MsState& st = sw.sts[w];
+        confl += st.conflicts;
+        uint32_t inst = w % n_instances;
+        if (st.status < 0) {
+            set_error(&s, status_text(st.status));
+            rc = st.status == MS_ST_ERR_INTERNAL ? MI355SAT_ERR_STATE : MI355SAT_ERR_OOM;
+        }
+        if (sw.results[inst] != MI355SAT_INTERRUPTED) continue;
+        if (st.status == MS_ST_SAT) { sw.results[inst] = MI355SAT_SAT; sw.winner[inst] = (int32_t)w; sw.decided++; }
+        else if (st.status == MS_ST_UNSAT) { sw.results[inst] = MI355SAT_UNSAT; sw.winner[inst] = (int32_t)w; sw.decided++; }
+    }
+    sw.conflicts = confl;
+    if (s.opts.verbose) {
+        uint64_t props = 0;
+        for (auto& st : sw.sts) props += st.propagations;
+        fprintf(stderr, "[mi355sat] slice: decided %u/%u conflicts=%llu props=%llu kernel=%.3fs\n", sw.decided,
+                n_instances, (unsigned long long)confl, (unsigned long long)props, s.stats.kernel_seconds);
+    }
+    if (rc) return rc;
+    // clear the stop-on-any latch and park the still-running workers of decided instances
+    HIPCHK(hipMemsetAsync(s.d_any_done.p, 0, sizeof(int32_t), s.stream));
+    if (n_instances > 1 && sw.decided > 0 && sw.decided < n_instances) {
+        for (uint32_t w = 0; w < s.n_workers; w++) {
+            uint32_t inst = w % n_instances;
+            if (sw.results[inst] != MI355SAT_INTERRUPTED && sw.sts[w].status == MS_ST_RUNNING) {
+                int32_t parked = MS_ST_PARKED;
+                HIPCHK(hipMemcpyAsync(s.d_slabs.p + (size_t)w * s.L.slab_bytes + s.L.state + offsetof(MsState, status),
+                                      &parked, sizeof parked, hipMemcpyHostToDevice, s.stream));
+                sw.sts[w].status = MS_ST_PARKED;
+            }
+        }
+        HIPCHK(hipStreamSynchronize(s.stream));
+    }
+    return 0;
+}
+
+bool sweep_finished(const mi355sat& s, const Sweep& sw) {
+    if (!sw.active) return true;
+    if (sw.decided == sw.n_instances || (sw.stop_at_first && sw.decided > 0)) return true;
+    if (s.interrupted.load() || *s.stop_flag) return true;
+    if (s.opts.conflict_budget > 0 && (int64_t)sw.conflicts >= s.opts.conflict_budget) return true;
+    return false;
+}
+
+void sweep_end(mi355sat& s, Sweep& sw) {
+    if (sw.active) accumulate_stats(s, sw.sts);
+    sw.active = false;
+}
+
+int run_search(mi355sat& s, const std::vector<int32_t>& assump, const std::vector<uint64_t>& assump_off,
+               uint32_t n_instances, std::vector<int32_t>& results, std::vector<int32_t>& winner, bool stop_at_first) {
+    Sweep sw;
+    int rc = sweep_begin(s, sw, assump, assump_off, n_instances, stop_at_first);
+    while (!rc && !sweep_finished(s, sw)) rc = sweep_step(s, sw);
+    sweep_end(s, sw);
+    results = sw.results;
+    winner = sw.winner;
+    return rc;
+}
+
+}  // namespace
+
+struct SweepHolder { Sweep sw; mi355sat_stats_t base; };
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* mi355sat_signature(void) { return "mi355sat 0.1 (HIP/gfx950 wave-parallel CDCL)"; }
+
+const char* mi355sat_last_error(const mi355sat* s) {
+    if (s) return s->err.c_str();
+    std::lock_guard<std::mutex> g(g_new_error_mu);
+    return g_new_error.c_str();
+}
+
+mi355sat* mi355sat_new(const mi355sat_opts* opts) {
+    auto fail = [](const std::string& m) -> mi355sat* {
+        std::lock_guard<std::mutex> g(g_new_error_mu);
+        g_new_error = m;
+        return nullptr;
+    };
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(std::string("no usable HIP device (mi355sat has no CPU fallback): ") +
+                    (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    mi355sat* s = new (std::nothrow) mi355sat;
+    if (!s) return fail("out of host memory");
+    if (opts) s->opts = *opts;
+    int dev = 0;
+    if (opts && opts->device >= 0) dev = opts->device;
+    else if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= n) { delete s; return fail("device ordinal out of range"); }
+    s->device = dev;
+    try {
+        HIPCHK(hipSetDevice(dev));
+        HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&s->ev0));
+        HIPCHK(hipEventCreate(&s->ev1));
+        HIPCHK(hipHostMalloc((void**)&s->stop_flag, sizeof(int32_t), hipHostMallocMapped));
+        *s->stop_flag = 0;
+    } catch (HipErr& he) {
+        std::string m = he.msg;
+        delete s;
+        return fail(m);
+    }
+    return s;
+}
+
+void mi355sat_free(mi355sat* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    delete s->sweep;
+    s->d_cl_off.release(); s->d_bin_off.release(); s->d_cl_lits.release(); s->d_bin_lits.release();
+    s->d_template.release(); s->d_slabs.release(); s->d_states.release(); s->d_any_done.release();
+    s->d_assump.release(); s->d_script.release(); s->d_assump_off.release(); s->d_script_off.release();
+    if (s->stop_flag) (void)hipHostFree(s->stop_flag);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int mi355sat_reserve(mi355sat* s, uint64_t n_vars) {
+    if (!s) return MI355SAT_ERR_ARG;
+    if (n_vars > s->max_var) s->max_var = n_vars;
+    s->stats.max_var = s->max_var;
+    return 0;
+}
+
+static int add_clause_impl(mi355sat* s, const int32_t* l, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) {
+        int32_t d = l[i];
+        if (d == 0 || d == INT32_MIN) { s->err = "literal 0 inside a clause"; return MI355SAT_ERR_ARG; }
+        uint64_t v = (uint64_t)(d < 0 ? -(int64_t)d : d);
+        if (v > (1u << 28)) { s->err = "variable index too large"; return MI355SAT_ERR_ARG; }
+        if (v > s->max_var) s->max_var = v;
+    }
+    s->lits.insert(s->lits.end(), l, l + n);
+    s->offs.push_back(s->lits.size());
+    s->stats.n_clauses++;
+    s->stats.max_var = s->max_var;
+    s->stats.avg_clause_len = (double)s->lits.size() / (double)s->stats.n_clauses;
+    return 0;
+}
+
+int mi355sat_add_cnf(mi355sat* s, const int32_t* lits, const uint64_t* offsets, uint64_t n_clauses) {
+    if (!s || (n_clauses && (!offsets || (!lits && offsets[n_clauses] > offsets[0])))) return MI355SAT_ERR_ARG;
+    try {
+        for (uint64_t c = 0; c < n_clauses; c++) {
+            if (offsets[c + 1] < offsets[c]) { s->err = "offsets not monotone"; return MI355SAT_ERR_ARG; }
+            int rc = add_clause_impl(s, lits + offsets[c], offsets[c + 1] - offsets[c]);
+            if (rc) return rc;
+        }
+    } catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
+    return 0;
+}
+
+int mi355sat_add(mi355sat* s, int32_t lit_or_0) {
+    if (!s) return MI355SAT_ERR_ARG;
+    try {
+        if (lit_or_0 != 0) { s->pending.push_back(lit_or_0); return 0; }
+        int rc = add_clause_impl(s, s->pending.data(), s->pending.size());
+        s->pending.clear();
+        return rc;
+    } catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
+}
+
+void mi355sat_interrupt(mi355sat* s) {
+    if (!s) return;
+    s->interrupted.store(1);
+    if (s->stop_flag) __atomic_store_n(s->stop_flag, 1, __ATOMIC_SEQ_CST);
+}
+
+int mi355sat_set_proof_path(mi355sat* s, const char* path) {
+    if (!s) return MI355SAT_ERR_ARG;
+    s->proof_path = path ? path : "";
+    return 0;
+}
+
+int mi355sat_solve(mi355sat* s) {
+    if (!s) return MI355SAT_ERR_ARG;
+    if (!s->pending.empty()) { s->err = "solve() called inside an unterminated clause"; return MI355SAT_ERR_STATE; }
+    const double t0 = now_s();
+    int result;
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        std::vector<int32_t> assump;
+        std::vector<uint64_t> aoff{0, 0};
+        std::vector<int32_t> results, winner;
+        int rc = run_search(*s, assump, aoff, 1, results, winner, true);
+        if (rc) { s->stats.solve_seconds += now_s() - t0; return rc; }
+        result = results[0];
+        s->model.clear();
+        if (result == MI355SAT_SAT) fetch_model(*s, (uint32_t)winner[0], s->model, s->max_var);
+    } catch (HipErr& he) {
+        s->err = he.msg;
+        s->stats.solve_seconds += now_s() - t0;
+        return MI355SAT_ERR_HIP;
+    } catch (std::bad_alloc&) {
+        s->err = "out of host memory";
+        return MI355SAT_ERR_OOM;
+    }
+    if (result == MI355SAT_SAT) s->stats.n_sat++;
+    else if (result == MI355SAT_UNSAT) s->stats.n_unsat++;
+    else s->stats.n_terminated++;
+    s->stats.solve_seconds += now_s() - t0;
+    return result;
+}
+
+int mi355sat_solve_batch(mi355sat* s, const int32_t* assumps, const uint64_t* assump_offsets, uint64_t n_instances,
+                         int32_t* results_out, int stop_at_first) {
+    if (!s || !assump_offsets || !results_out || n_instances == 0) return MI355SAT_ERR_ARG;
+    const double t0 = now_s();
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        std::vector<uint64_t> aoff(assump_offsets, assump_offsets + n_instances + 1);
+        for (auto& o : aoff) o -= assump_offsets[0];
+        std::vector<int32_t> assump;
+        if (aoff.back()) assump.assign(assumps + assump_offsets[0], assumps + assump_offsets[n_instances]);
+        std::vector<int32_t> results, winner;
+        int rc = run_search(*s, assump, aoff, (uint32_t)n_instances, results, winner, stop_at_first != 0);
+        if (rc) { s->stats.solve_seconds += now_s() - t0; return rc; }
+        s->batch_models.assign(n_instances, {});
+        for (uint64_t i = 0; i < n_instances; i++) {
+            results_out[i] = results[i];
+            if (results[i] == MI355SAT_SAT && winner[i] >= 0) fetch_model(*s, (uint32_t)winner[i], s->batch_models[i], s->max_var);
+            if (results[i] == MI355SAT_SAT) s->stats.n_sat++;
+            else if (results[i] == MI355SAT_UNSAT) s->stats.n_unsat++;
+            else s->stats.n_terminated++;
+        }
+    } catch (HipErr& he) {
+        s->err = he.msg;
+        s->stats.solve_seconds += now_s() - t0;
+        return MI355SAT_ERR_HIP;
+    } catch (std::bad_alloc&) {
+        s->err = "out of host memory";
+        return MI355SAT_ERR_OOM;
+    }
+    s->stats.solve_seconds += now_s() - t0;
+    return 0;
+}
+
+int mi355sat_propagate_batch(mi355sat* s, const int32_t* decisions, const uint64_t* decision_offsets,
+                             uint64_t n_instances, int8_t* out_values, uint64_t n_vars, int32_t* out_conflict,
+                             int32_t* out_trail_len, int32_t repeat) {
+    if (!s || !decision_offsets || n_instances == 0) return MI355SAT_ERR_ARG;
+    const double t0 = now_s();
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        Prepared P;
+        prepare(*s, /*simplify=*/false, P);
+        if (P.unsat) {  // contradictory unit clauses: every instance conflicts before any decision
+            for (uint64_t i = 0; i < n_instances; i++) {
+                if (out_conflict) out_conflict[i] = 1;
+                if (out_trail_len) out_trail_len[i] = 0;
+            }
+            if (out_values) memset(out_values, 0, n_instances * n_vars);
+            return 0;
+        }
+        std::vector<uint64_t> soff(decision_offsets, decision_offsets + n_instances + 1);
+        for (auto& o : soff) o -= decision_offsets[0];
+        std::vector<int32_t> script(soff.back());
+        uint32_t max_script = 0;
+        for (uint64_t i = 0; i < n_instances; i++) max_script = std::max<uint32_t>(max_script, (uint32_t)(soff[i + 1] - soff[i]));
+        for (uint64_t k = 0; k < soff.back(); k++) {
+            int32_t d = decisions[decision_offsets[0] + k];
+            if (d == 0 || (uint64_t)(d < 0 ? -(int64_t)d : d) > P.n_vars) throw HipErr{"decision literal out of range"};
+            script[k] = to_internal(d);
+        }
+        upload_formula(*s, P, 0, max_script, (uint32_t)n_instances);
+        if (s->n_workers < n_instances) throw HipErr{"not enough device memory for the batch"};
+        std::vector<MsState> sts;
+        if (repeat < 1) repeat = 1;
+        for (int r = 0; r < repeat; r++) {
+            reset_workers(*s);
+            customize(*s, nullptr, nullptr, &script, &soff, (uint32_t)n_instances);
+            launch_slice(*s, 1, false);
+        }
+        gather_states(*s, sts);
+        for (uint64_t i = 0; i < n_instances; i++) {
+            if (sts[i].status < 0) { s->err = status_text(sts[i].status); return MI355SAT_ERR_OOM; }
+            if (out_conflict) out_conflict[i] = sts[i].status == MS_ST_UNSAT ? 1 : 0;
+            if (out_trail_len) out_trail_len[i] = sts[i].trail_n;
+        }
+        // counters of the last repeat only, scaled
+        {
+            std::vector<MsState> one = sts;
+            accumulate_stats(*s, one);
+            if (repeat > 1) {
+                mi355sat_stats_t& o = s->stats;
+                uint64_t props = 0, nw = 0, ncl = 0, nm = 0, ne = 0;
+                for (auto& st : sts) { props += st.propagations; nw += st.n_watch; ncl += st.n_cl_lit; nm += st.n_move; ne += st.n_enq; }
+                uint64_t k = (uint64_t)(repeat - 1);
+                o.propagations += props * k; o.n_deq += props * k; o.n_watch += nw * k; o.n_cl_lit += ncl * k;
+                o.n_move += nm * k; o.n_enq += ne * k;
+            }
+        }
+        if (out_values) {
+            std::vector<uint8_t> raw(n_instances * (size_t)P.n_vars);
+            if (P.n_vars)
+                HIPCHK(hipMemcpy2D(raw.data(), P.n_vars, s->d_slabs.p + s->L.val, s->L.slab_bytes, P.n_vars,
+                                   n_instances, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < n_instances; i++)
+                for (uint64_t v = 0; v < n_vars; v++) {
+                    uint8_t x = v < P.n_vars ? raw[i * P.n_vars + v] : MS_VAL_UNDEF;
+                    out_values[i * n_vars + v] = x == MS_VAL_TRUE ? 1 : (x == MS_VAL_FALSE ? -1 : 0);
+                }
+        }
+    } catch (HipErr& he) {
+        s->err = he.msg;
+        s->stats.solve_seconds += now_s() - t0;
+        return MI355SAT_ERR_HIP;
+    } catch (std::bad_alloc&) {
+        s->err = "out of host memory";
+        return MI355SAT_ERR_OOM;
+    }
+    s->stats.solve_seconds += now_s() - t0;
+    return 0;
+}
+
+int mi355sat_sweep_begin(mi355sat* s, const int32_t* assumps, const uint64_t* assump_offsets, uint64_t n_instances) {
+    if (!s || !assump_offsets || n_instances == 0) return MI355SAT_ERR_ARG;
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        std::vector<uint64_t> aoff(assump_offsets, assump_offsets + n_instances + 1);
+        for (auto& o : aoff) o -= assump_offsets[0];
+        std::vector<int32_t> assump;
+        if (aoff.back()) assump.assign(assumps + assump_offsets[0], assumps + assump_offsets[n_instances]);
+        delete s->sweep;
+        s->sweep = new SweepHolder;
+        s->sweep->base = s->stats;
+        return sweep_begin(*s, s->sweep->sw, assump, aoff, (uint32_t)n_instances, false);
+    } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
+    catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
+}
+
+int mi355sat_sweep_step(mi355sat* s, int32_t* results_out, uint64_t* n_decided) {
+    if (!s || !s->sweep) return MI355SAT_ERR_STATE;
+    const double t0 = now_s();
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        Sweep& sw = s->sweep->sw;
+        int rc = sweep_step(*s, sw);
+        if (results_out) for (uint32_t i = 0; i < sw.n_instances; i++) results_out[i] = sw.results[i];
+        if (n_decided) *n_decided = sw.decided;
+        // running totals so that stats() is meaningful between steps
+        mi355sat_stats_t keep = s->stats;
+        s->stats = s->sweep->base;
+        s->stats.kernel_seconds = keep.kernel_seconds;
+        s->stats.kernel_launches = keep.kernel_launches;
+        s->stats.solve_seconds = keep.solve_seconds + (now_s() - t0);
+        accumulate_stats(*s, sw.sts);
+        return rc;
+    } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
+    catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
+}
+
+int mi355sat_sweep_end(mi355sat* s) {
+    if (!s || !s->sweep) return MI355SAT_ERR_STATE;
+    try {
+        Sweep& sw = s->sweep->sw;
+        s->batch_models.assign(sw.n_instances, {});
+        for (uint32_t i = 0; i < sw.n_instances; i++)
+            if (sw.results[i] == MI355SAT_SAT && sw.winner[i] >= 0)
+                fetch_model(*s, (uint32_t)sw.winner[i], s->batch_models[i], s->max_var);
+        delete s->sweep;
+        s->sweep = nullptr;
+        return 0;
+    } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
+}
+
+int32_t mi355sat_val(mi355sat* s, int32_t lit) {
+    if (!s || lit == 0) return 0;
+    uint64_t v = (uint64_t)(lit < 0 ? -(int64_t)lit : lit);
+    if (v > s->model.size()) return 0;
+    int8_t m = s->model[v - 1];
+    if (m == 0) return 0;
+    bool is_true = (lit > 0) == (m > 0);
+    return is_true ? lit : -lit;
+}
+
+int mi355sat_model(mi355sat* s, int8_t* out, uint64_t n_vars) {
+    if (!s || !out) return MI355SAT_ERR_ARG;
+    if (s->model.empty() && s->max_var) { s->err = "no model (last result was not SAT)"; return MI355SAT_ERR_STATE; }
+    for (uint64_t v = 0; v < n_vars; v++) out[v] = v < s->model.size() ? s->model[v] : 0;
+    return 0;
+}
+
+int mi355sat_model_of(mi355sat* s, uint64_t instance, int8_t* out, uint64_t n_vars) {
+    if (!s || !out) return MI355SAT_ERR_ARG;
+    if (instance >= s->batch_models.size() || s->batch_models[instance].empty()) {
+        s->err = "no model for that instance";
+        return MI355SAT_ERR_STATE;
+    }
+    const auto& m = s->batch_models[instance];
+    for (uint64_t v = 0; v < n_vars; v++) out[v] = v < m.size() ? m[v] : 0;
+    return 0;
+}
+
+int mi355sat_stats(const mi355sat* s, mi355sat_stats_t* out) {
+    if (!s || !out) return MI355SAT_ERR_ARG;
+    *out = s->stats;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+"""Python view of the solver boundary (include/mi355sat.h).
+
+`Mi355Sat` mirrors the part of rustsat's `Solve + Interrupt + SolveStats` that
+the reference exercises:
+
+    GlucoseSimp::default()            crates/repl/src/main.rs:295      -> Mi355Sat()
+    solver.add_cnf(cnf)               crates/repl/src/solver_runner.rs:12
+    solver.interrupter()              crates/repl/src/solver_runner.rs:13
+    interrupter.interrupt()           crates/repl/src/main.rs:316
+    solver.solve() -> SolverResult    crates/repl/src/solver_runner.rs:16
+    solver.full_solution()            crates/repl/src/main.rs:329
+    solver.stats()                    crates/repl/src/main.rs:363
+
+plus the two batched entry points the sharded sweep and the BCP configuration
+use (solve_batch / propagate_batch).  Errors come back as `SolverError`, the
+analogue of the reference's `anyhow::Result`.
+"""
+import ctypes
+import enum
+
+import numpy as np
+
+from . import _lib
+
+
+class SolverResult(enum.Enum):  # rustsat::solvers::SolverResult
+    Sat = 10
+    Unsat = 20
+    Interrupted = 0
+
+
+class SolverError(RuntimeError):
+    pass
+
+
+class Mi355SatOpts(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("workers", ctypes.c_int32), ("conflict_budget", ctypes.c_int64),
+                ("slice_conflicts", ctypes.c_int32), ("seed", ctypes.c_uint64), ("verbose", ctypes.c_int32),
+                ("reduce_first", ctypes.c_int32), ("reduce_inc", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+
+
+class Mi355SatStats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in
+                ("propagations", "decisions", "conflicts", "restarts", "learnts", "learnt_literals",
+                 "reduce_dbs", "n_clauses", "max_var")] + \
+               [("avg_clause_len", ctypes.c_double), ("solve_seconds", ctypes.c_double),
+                ("kernel_seconds", ctypes.c_double), ("kernel_launches", ctypes.c_uint64)] + \
+               [(n, ctypes.c_uint64) for n in
+                ("n_deq", "n_watch", "n_cl_lit", "n_move", "n_enq", "n_sat", "n_unsat", "n_terminated")] + \
+               [("reserved", ctypes.c_uint64 * 8)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+def algorithmic_bytes(stats):
+    """12*n_deq + 9*n_watch + 5*n_cl_lit + 8*n_move + 13*n_enq."""
+    return (12 * stats["n_deq"] + 9 * stats["n_watch"] + 5 * stats["n_cl_lit"] + 8 * stats["n_move"]
+            + 13 * stats["n_enq"])
+
+
+def _bind(L):
+    vp = ctypes.c_void_p
+    L.mi355sat_new.restype = vp
+    L.mi355sat_new.argtypes = [ctypes.POINTER(Mi355SatOpts)]
+    L.mi355sat_free.argtypes = [vp]
+    L.mi355sat_signature.restype = ctypes.c_char_p
+    L.mi355sat_last_error.restype = ctypes.c_char_p
+    L.mi355sat_last_error.argtypes = [vp]
+    L.mi355sat_add_cnf.argtypes = [vp, vp, vp, ctypes.c_uint64]
+    L.mi355sat_add.argtypes = [vp, ctypes.c_int32]
+    L.mi355sat_reserve.argtypes = [vp, ctypes.c_uint64]
+    L.mi355sat_solve.argtypes = [vp]
+    L.mi355sat_solve_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_int]
+    L.mi355sat_sweep_begin.argtypes = [vp, vp, vp, ctypes.c_uint64]
+    L.mi355sat_sweep_step.argtypes = [vp, vp, vp]
+    L.mi355sat_sweep_end.argtypes = [vp]
+    L.mi355sat_propagate_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, ctypes.c_int32]
+    L.mi355sat_val.argtypes = [vp, ctypes.c_int32]
+    L.mi355sat_val.restype = ctypes.c_int32
+    L.mi355sat_model.argtypes = [vp, vp, ctypes.c_uint64]
+    L.mi355sat_model_of.argtypes = [vp, ctypes.c_uint64, vp, ctypes.c_uint64]
+    L.mi355sat_interrupt.argtypes = [vp]
+    L.mi355sat_stats.argtypes = [vp, ctypes.POINTER(Mi355SatStats)]
+    L.mi355sat_set_proof_path.argtypes = [vp, ctypes.c_char_p]
+    return L
+
+
+_bound = {}
+
+
+def _p(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+class Interrupter:
+    """`S::Interrupter`: Send + 'static, callable from another thread while solve() runs."""
+
+    def __init__(self, lib, handle_ref):
+        self._lib, self._ref = lib, handle_ref
+
+    def interrupt(self):
+        h = self._ref[0]
+        if h:
+            self._lib.mi355sat_interrupt(h)
+
+
+class Mi355Sat:
+    def __init__(self, device=-1, workers=0, conflict_budget=0, slice_conflicts=0, seed=0, verbose=0,
+                 reduce_first=0, reduce_inc=0, _lib_override=None):
+        # _lib_override: test hook (the wavefront-emulator build under tests/emu); the product
+        # always binds the HIP library and fails loudly without it.
+        raw = _lib_override if _lib_override is not None else _lib.solver_lib()
+        if id(raw) not in _bound:
+            _bound[id(raw)] = _bind(raw)
+        self._L = _bound[id(raw)]
+        opts = Mi355SatOpts(device=device, workers=workers, conflict_budget=conflict_budget,
+                            slice_conflicts=slice_conflicts, seed=seed, verbose=verbose,
+                            reduce_first=reduce_first, reduce_inc=reduce_inc)
+        self._h = self._L.mi355sat_new(ctypes.byref(opts))
+        if not self._h:
+            raise SolverError("mi355sat_new failed: " + (self._L.mi355sat_last_error(None) or b"").decode())
+        self._ref = [self._h]
+        self._n_vars = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mi355sat_free(self._h)
+            self._h = None
+            self._ref[0] = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise SolverError(f"{what} failed ({rc}): " + (self._L.mi355sat_last_error(self._h) or b"").decode())
+        return rc
+
+    @staticmethod
+    def signature():
+        return _bind(_lib.solver_lib()).mi355sat_signature().decode()
+
+    # ---- Solve
+    def add_cnf(self, lits, offsets):
+        lits = np.ascontiguousarray(lits, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(self._L.mi355sat_add_cnf(self._h, _p(lits), _p(offsets), len(offsets) - 1), "add_cnf")
+        if lits.size:
+            self._n_vars = max(self._n_vars, int(np.abs(lits).max()))
+
+    def add_clause(self, clause):
+        for l in clause:
+            self._check(self._L.mi355sat_add(self._h, int(l)), "add")
+            self._n_vars = max(self._n_vars, abs(int(l)))
+        self._check(self._L.mi355sat_add(self._h, 0), "add")
+
+    def reserve(self, n_vars):
+        self._check(self._L.mi355sat_reserve(self._h, n_vars), "reserve")
+        self._n_vars = max(self._n_vars, n_vars)
+
+    def interrupter(self):
+        return Interrupter(self._L, self._ref)
+
+    def solve(self):
+        return SolverResult(self._check(self._L.mi355sat_solve(self._h), "solve"))
+
+    def solve_batch(self, assumption_sets, stop_at_first=False):
+        """assumption_sets: list of lists of DIMACS literals.  Returns [SolverResult]."""
+        offs = np.zeros(len(assumption_sets) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(a) for a in assumption_sets])
+        flat = np.asarray([l for a in assumption_sets for l in a], dtype=np.int32)
+        res = np.zeros(len(assumption_sets), dtype=np.int32)
+        self._check(self._L.mi355sat_solve_batch(self._h, _p(flat), _p(offs), len(assumption_sets), _p(res),
+                                                 1 if stop_at_first else 0), "solve_batch")
+        return [SolverResult(int(r)) for r in res]
+
+    # stepwise form of solve_batch (one kernel slice per step); bench.py times these
+    def sweep_begin(self, assumption_sets):
+        offs = np.zeros(len(assumption_sets) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(a) for a in assumption_sets])
+        flat = np.asarray([l for a in assumption_sets for l in a], dtype=np.int32)
+        self._sweep_n = len(assumption_sets)
+        self._check(self._L.mi355sat_sweep_begin(self._h, _p(flat), _p(offs), self._sweep_n), "sweep_begin")
+
+    def sweep_step(self):
+        """Returns ([SolverResult per instance], n_decided)."""
+        res = np.zeros(self._sweep_n, dtype=np.int32)
+        nd = ctypes.c_uint64(0)
+        self._check(self._L.mi355sat_sweep_step(self._h, _p(res), ctypes.byref(nd)), "sweep_step")
+        return [SolverResult(int(r)) for r in res], nd.value
+
+    def sweep_end(self):
+        self._check(self._L.mi355sat_sweep_end(self._h), "sweep_end")
+
+    def propagate_batch(self, decision_sets, n_vars=None, repeat=1, want_values=True):
+        """Scripted BCP: returns (conflict int32[n], values int8[n, n_vars] or None, trail_len int32[n])."""
+        n = len(decision_sets)
+        n_vars = self._n_vars if n_vars is None else n_vars
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(a) for a in decision_sets])
+        flat = np.asarray([l for a in decision_sets for l in a], dtype=np.int32)
+        confl = np.zeros(n, dtype=np.int32)
+        tl = np.zeros(n, dtype=np.int32)
+        vals = np.zeros((n, n_vars), dtype=np.int8) if want_values else None
+        self._check(self._L.mi355sat_propagate_batch(self._h, _p(flat), _p(offs), n, _p(vals) if want_values else None,
+                                                     n_vars, _p(confl), _p(tl), repeat), "propagate_batch")
+        return confl, vals, tl
+
+    def lit_val(self, lit):
+        return self._L.mi355sat_val(self._h, int(lit))
+
+    def full_solution(self, n_vars=None):
+        """Assignment for vars 1..n_vars as int8: 1 true, -1 false, 0 unknown."""
+        n_vars = self._n_vars if n_vars is None else n_vars
+        out = np.zeros(n_vars, dtype=np.int8)
+        self._check(self._L.mi355sat_model(self._h, _p(out), n_vars), "full_solution")
+        return out
+
+    def solution_of(self, instance, n_vars=None):
+        n_vars = self._n_vars if n_vars is None else n_vars
+        out = np.zeros(n_vars, dtype=np.int8)
+        self._check(self._L.mi355sat_model_of(self._h, instance, _p(out), n_vars), "solution_of")
+        return out
+
+    # ---- SolveStats
+    def stats(self):
+        st = Mi355SatStats()
+        self._check(self._L.mi355sat_stats(self._h, ctypes.byref(st)), "stats")
+        return st.as_dict()
+
+    def max_var(self):
+        return self._n_vars
