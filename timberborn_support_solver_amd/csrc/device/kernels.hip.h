@@ -56,6 +56,7 @@ struct Wk {
     volatile int32_t* ring;
     volatile uint32_t* claim;
     volatile uint32_t* ov_cnt;
+    volatile uint32_t* hist;   // 64 words, reduce_db
     // hot uniform scalars
     int lane;
     int trail_n, qhead, n_levels, ring_lo;
@@ -560,28 +561,46 @@ DEV Learnt analyze(Wk& w) {
     return Learnt{n_out, bt, lbd};
 }
 
-// Store the clause in learnt_buf[0..n) and attach it.  Returns its cref (or -1).
-DEV int add_learnt(Wk& w, int n, uint32_t lbd) {
-    if (w.n_learnts >= w.learnt_cap || w.lc_lits_n + (uint32_t)n > w.learnt_lit_cap) {
-        w.status = MS_ST_ERR_LEARNT;
-        return -1;
-    }
-    const uint32_t k = w.n_learnts, o = w.lc_lits_n;
-    for (int i = w.lane; i < n; i += MS_WAVE) w.lc_lits[o + i] = w.learnt_buf[i];
-    const int l0 = uni(w.learnt_buf[0]), l1 = uni(w.learnt_buf[1]);
-    const int cref = (int)(w.n_orig + k);
-    if (w.lane == 0) {
-        w.lc_off[k] = o;
-        w.lc_off[k + 1] = o + (uint32_t)n;
-        w.lc_lbd[k] = lbd;
-        w.wl[cref] = make_int2(l0, l1);
-    }
-    w.n_learnts++;
-    w.lc_lits_n += (uint32_t)n;
+// ---- watch pool garbage collection ---------------------------------------------------
+// Lists that outgrow their slot are moved to the top of a bump pool and leave a
+// hole behind.  The rebuild lays every list out again, densely, straight from the
+// per-clause watched-literal pairs (no read of the old pool): count, exclusive scan
+// over the 2*n_vars lists (wave prefix sums), fill.  Runs at a propagation fixpoint.
+DEV void rebuild_watches(Wk& w) {
+    const uint32_t nlist = 2 * w.n_vars;
+    const uint32_t ncl = w.n_orig + w.n_learnts;
+    for (uint32_t t = (uint32_t)w.lane; t < nlist; t += MS_WAVE) w.w_size[t] = 0;
     wave_fence();
-    if (!list_push_uniform(w, l0 ^ 1, cref, l1)) return -1;
-    if (!list_push_uniform(w, l1 ^ 1, cref, l0)) return -1;
-    return cref;
+    for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
+        int2 ww = w.wl[c];
+        atomicAdd(&w.w_size[ww.x ^ 1], 1u);
+        atomicAdd(&w.w_size[ww.y ^ 1], 1u);
+    }
+    wave_fence();
+    uint32_t run = 0;
+    for (uint32_t t0 = 0; t0 < nlist; t0 += MS_WAVE) {
+        uint32_t t = t0 + (uint32_t)w.lane;
+        uint32_t sz = t < nlist ? w.w_size[t] : 0;
+        uint32_t cap = t < nlist ? sz + (sz >> 1) + 4 : 0;
+        uint32_t incl = cap;
+        for (int o = 1; o < MS_WAVE; o <<= 1) {
+            uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (w.lane >= o) incl += x;
+        }
+        if (t < nlist) { w.w_base[t] = run + incl - cap; w.w_cap[t] = cap; w.w_size[t] = 0; }
+        run += (uint32_t)bcast((int)incl, 63);
+    }
+    if (run > w.pool_cap) { w.status = MS_ST_ERR_POOL; return; }
+    w.pool_top = run;
+    wave_fence();
+    for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
+        int2 ww = w.wl[c];
+        uint32_t pa = atomicAdd(&w.w_size[ww.x ^ 1], 1u);
+        w.pool[w.w_base[ww.x ^ 1] + pa] = make_int2((int)c, ww.y);
+        uint32_t pb = atomicAdd(&w.w_size[ww.y ^ 1], 1u);
+        w.pool[w.w_base[ww.y ^ 1] + pb] = make_int2((int)c, ww.x);
+    }
+    wave_fence();
 }
 
 // ---- learnt clause database reduction ---------------------------------------
@@ -676,21 +695,11 @@ DEV void reduce_db(Wk& w, volatile uint32_t* hist /* 64 LDS words */) {
         wave_fence();
     }
     if (w.lane == 0) w.lc_off[nk] = nlits;
-    // pass 2: rewrite watch lists (one list per lane)
-    const uint32_t nlist = 2 * w.n_vars;
-    for (uint32_t t = (uint32_t)w.lane; t < nlist; t += MS_WAVE) {
-        uint32_t base = w.w_base[t], s = w.w_size[t], jj = 0;
-        for (uint32_t i = 0; i < s; i++) {
-            int2 e = w.pool[base + i];
-            if ((uint32_t)e.x >= w.n_orig) {
-                uint32_t m = w.remap[(uint32_t)e.x - w.n_orig];
-                if (m == 0xffffffffu) continue;
-                e.x = (int)(w.n_orig + m);
-            }
-            w.pool[base + jj++] = e;
-        }
-        w.w_size[t] = jj;
-    }
+    // pass 2: lay the watch lists out again without the deleted clauses (also collects pool garbage)
+    w.n_learnts = nk;
+    w.lc_lits_n = nlits;
+    wave_fence();
+    rebuild_watches(w);
     // pass 3: reasons of assigned variables
     for (int i = w.lane; i < w.trail_n; i += MS_WAVE) {
         int v = w.trail[i] >> 1;
@@ -700,6 +709,33 @@ DEV void reduce_db(Wk& w, volatile uint32_t* hist /* 64 LDS words */) {
     w.n_learnts = nk;
     w.lc_lits_n = nlits;
     wave_fence();
+}
+
+// Store the clause in learnt_buf[0..n) and attach it.  Returns its cref (or -1).
+DEV int add_learnt(Wk& w, int n, uint32_t lbd) {
+    if (w.n_learnts >= w.learnt_cap || w.lc_lits_n + (uint32_t)n > w.learnt_lit_cap) {
+        reduce_db(w, w.hist);  // store full before the scheduled reduction: reduce now (state is consistent here)
+        if (w.n_learnts >= w.learnt_cap || w.lc_lits_n + (uint32_t)n > w.learnt_lit_cap) {
+            w.status = MS_ST_ERR_LEARNT;
+            return -1;
+        }
+    }
+    const uint32_t k = w.n_learnts, o = w.lc_lits_n;
+    for (int i = w.lane; i < n; i += MS_WAVE) w.lc_lits[o + i] = w.learnt_buf[i];
+    const int l0 = uni(w.learnt_buf[0]), l1 = uni(w.learnt_buf[1]);
+    const int cref = (int)(w.n_orig + k);
+    if (w.lane == 0) {
+        w.lc_off[k] = o;
+        w.lc_off[k + 1] = o + (uint32_t)n;
+        w.lc_lbd[k] = lbd;
+        w.wl[cref] = make_int2(l0, l1);
+    }
+    w.n_learnts++;
+    w.lc_lits_n += (uint32_t)n;
+    wave_fence();
+    if (!list_push_uniform(w, l0 ^ 1, cref, l1)) return -1;
+    if (!list_push_uniform(w, l1 ^ 1, cref, l0)) return -1;
+    return cref;
 }
 
 // ---- worker load / store -------------------------------------------------------
@@ -760,7 +796,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov;
+    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist;
     if (w.lane == 0) s_ov = 0;
     wk_bind(w, sh, L, slabs + (size_t)wid * L.slab_bytes);
     MsState* st = w.st;
@@ -824,11 +860,14 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
                 restarts++;
                 cancel_until(w, 0);
             }
-            if (conflicts >= next_reduce) {
+            if (conflicts >= next_reduce || w.n_learnts > w.learnt_cap - w.learnt_cap / 8 ||
+                w.lc_lits_n > w.learnt_lit_cap - w.learnt_lit_cap / 8) {
                 reduce_dbs++;
                 next_reduce = conflicts + prm.reduce_first + (u64)prm.reduce_inc * reduce_dbs;
                 reduce_db(w, s_hist);
             }
+            if (w.pool_top > w.pool_cap - w.pool_cap / 4) rebuild_watches(w);  // pool running low: collect holes
+            if (w.status != MS_ST_RUNNING) break;
             int next = -1;
             bool refuted = false;
             while (w.n_levels < n_assumps) {
@@ -873,7 +912,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov;
+    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = nullptr;
     if (w.lane == 0) s_ov = 0;
     wk_bind(w, sh, L, slabs + (size_t)wid * L.slab_bytes);
     lds_fence();

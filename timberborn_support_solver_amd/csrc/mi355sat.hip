@@ -150,6 +150,7 @@ struct mi355sat {
     MsShared sh{};
     MsLayout L{};
     uint32_t n_workers = 0;
+    uint64_t pool_init = 0;                    // watch-pool entries in use in the template
     // prepared formula facts
     bool trivially_unsat = false;
     std::vector<int8_t> fixed;                 // per var: 0 free, 1 true, -1 false (level-0 facts)
@@ -285,22 +286,26 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     L.n_orig = no;
     // capacities
     const uint64_t base_lits = P.cl_lits.size();
-    L.learnt_cap = (uint32_t)std::min<uint64_t>(1u << 17, std::max<uint64_t>(1u << 14, 2 * (uint64_t)no + 4096));
-    L.learnt_lit_cap = (uint32_t)std::min<uint64_t>(6u << 20, std::max<uint64_t>(1u << 19, 4 * base_lits));
+    L.learnt_cap = (uint32_t)std::min<uint64_t>(1u << 17, std::max<uint64_t>(1u << 15, 2 * (uint64_t)no + 4096));
+    L.learnt_lit_cap = (uint32_t)std::min<uint64_t>(4u << 20, std::max<uint64_t>(1u << 20, 8 * base_lits));
     L.vm_cap = 3 * nv + 256;
     L.assump_cap = assump_cap;
     L.script_cap = script_cap;
-    // watch capacities: list of literal t holds clauses watching ~t: at most occ(~t) originals
+    // watch lists: literal t's list holds the clauses currently watching ~t.  Initial slots get
+    // 50% + 4 entries of slack; a list that outgrows its slot moves to the top of the bump pool and
+    // the device compacts the pool again at every learnt-clause reduction (rebuild_watches).
     std::vector<uint32_t> cap(2 * (size_t)nv, 0);
-    for (int32_t l : P.cl_lits) cap[l ^ 1]++;
+    for (uint32_t c = 0; c < no; c++) { cap[P.cl_lits[P.cl_off[c]] ^ 1]++; cap[P.cl_lits[P.cl_off[c] + 1] ^ 1]++; }
     uint64_t pool_need = 0;
     std::vector<uint32_t> base(2 * (size_t)nv);
     for (size_t t = 0; t < cap.size(); t++) {
-        cap[t] += 4;
+        cap[t] += (cap[t] >> 1) + 4;
         base[t] = (uint32_t)pool_need;
         pool_need += cap[t];
     }
-    uint64_t pool_cap = pool_need + std::max<uint64_t>(pool_need / 2, 1u << 18);
+    // room for a dense rebuild with every learnt slot in use, plus 50% for relocations in between
+    uint64_t dense_max = 3 * ((uint64_t)no + L.learnt_cap) + 8 * (uint64_t)nv;
+    uint64_t pool_cap = dense_max + dense_max / 2 + (1u << 16);
     if (pool_cap > 0xfffffff0ull) throw HipErr{"formula too large (watch pool)"};
     L.pool_cap = (uint32_t)pool_cap;
     size_t off = 0;
@@ -345,6 +350,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     st->vm_end = (int32_t)nv;
     st->vm_search = (int32_t)nv - 1;
     st->pool_top = (uint32_t)pool_need;
+    s.pool_init = pool_need;
     st->next_reduce = s.opts.reduce_first > 0 ? (uint64_t)s.opts.reduce_first : 2000;
     memset(T + L.val, MS_VAL_UNDEF, nv);
     memset(T + L.phase, 1, nv);
@@ -418,7 +424,7 @@ void reset_workers(mi355sat& s) {
     for (uint32_t w = 0; w < s.n_workers; w++) {
         char* dst = s.d_slabs.p + (size_t)w * L.slab_bytes;
         HIPCHK(hipMemcpyAsync(dst, s.d_template.p, head, hipMemcpyDeviceToDevice, s.stream));
-        HIPCHK(hipMemcpyAsync(dst + L.pool, s.d_template.p + L.pool, 8 * (size_t)L.pool_cap,
+        HIPCHK(hipMemcpyAsync(dst + L.pool, s.d_template.p + L.pool, 8 * (size_t)s.pool_init,
                               hipMemcpyDeviceToDevice, s.stream));
     }
     HIPCHK(hipMemsetAsync(s.d_any_done.p, 0, sizeof(int32_t), s.stream));
@@ -584,8 +590,11 @@ int sweep_step(mi355sat& s, Sweep& sw) {
     if (s.opts.verbose) {
         uint64_t props = 0;
         for (auto& st : sw.sts) props += st.propagations;
-        fprintf(stderr, "[mi355sat] slice: decided %u/%u conflicts=%llu props=%llu kernel=%.3fs\n", sw.decided,
-                n_instances, (unsigned long long)confl, (unsigned long long)props, s.stats.kernel_seconds);
+        uint64_t nl = 0, ll = 0, lt = 0, llt = 0;
+        for (auto& st : sw.sts) { nl += st.n_learnts; ll += st.lc_lits_n; lt += st.learnt_total; llt += st.learnt_lits_total; }
+        fprintf(stderr, "[mi355sat] slice: decided %u/%u conflicts=%llu props=%llu kernel=%.3fs kept=%llu (avg len %.1f) learnt avg len %.1f\n",
+                sw.decided, n_instances, (unsigned long long)confl, (unsigned long long)props, s.stats.kernel_seconds,
+                (unsigned long long)nl, nl ? (double)ll / nl : 0.0, lt ? (double)llt / lt : 0.0);
     }
     if (rc) return rc;
     // clear the stop-on-any latch and park the still-running workers of decided instances
