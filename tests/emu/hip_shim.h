@@ -31,6 +31,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __shared__ static
 
@@ -91,6 +92,12 @@ template <class T>
 static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T>
 static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T>
+static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T>
+static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+// dynamic LDS: one static 160 KiB block per (sequentially executed) workgroup
+#define HIP_DYNAMIC_SHARED(type, var) static type var[163840 / sizeof(type)];
 
 // ---- runtime shims ------------------------------------------------------------------
 typedef int hipError_t;

@@ -8,21 +8,26 @@
 // Execution model: ONE 64-lane wavefront = one worker = one independent CDCL
 // search over its private slab (layout.h).  A workgroup is a single wave, so
 // there are no workgroup barriers; lanes cooperate through ballots, lane
-// shuffles and a little LDS:
-//   * BCP: the 64 lanes take 64 watchers (or 64 binary implications) of the
-//     dequeued literal at a time.  Watch lists are contiguous (cref, blocker)
-//     pairs -> one coalesced 512-byte read per chunk.  Kept watchers are
-//     compacted in place with ballot + prefix popcount.
+// shuffles and LDS:
+//   * BCP propagates up to 8 queue literals per step: the wave splits into G lane
+//     groups (G = 1/2/4/8 by queue length), one dequeued literal per group.  Each
+//     group streams that literal's three lists with coalesced reads: binary
+//     implications and ternary literal pairs from the SHARED read-only CSRs
+//     (no watches, no writes), and the private two-watched-literal list of the
+//     long and learnt clauses, compacting kept watchers in place with a
+//     group-masked ballot + prefix popcount.
+//   * the assignment lives in LDS, 2 bits per variable, when it fits (template
+//     parameter LV); every value lookup of BCP is then an LDS gather.
 //   * conflict detection is a ballot over the lanes' clause states; implied
-//     literals are deduplicated through a small LDS claim table (two lanes may
-//     imply the same or complementary literals in one chunk) and appended to the
-//     trail with a prefix popcount.
-//   * the propagation queue (the not-yet-propagated suffix of the trail) is
-//     staged in an LDS ring; the trail in HBM is only re-read on ring overflow.
-//   * analysis, minimisation, LBD, backjump and the move-to-front decision
-//     queue are wave-parallel over clause literals / trail segments.
+//     literals are deduplicated through an LDS claim table (lanes may imply the
+//     same or complementary literals in one step) and appended to the trail with a
+//     prefix popcount.
+//   * the propagation queue (the not-yet-propagated suffix of the trail) is staged
+//     in an LDS ring; the trail in HBM is only re-read on ring overflow.
+//   * analysis, minimisation, LBD, backjump, the move-to-front decision queue and
+//     the learnt-clause reduction are wave-parallel over literals / trail segments.
 // Integer / indexing work only: no MFMA.  The bound is memory latency and HBM
-// bandwidth on the private slabs; the shared clause literals sit in L2/MALL.
+// bandwidth on the private slabs; the shared CSRs sit in L2 / Infinity Cache.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -31,32 +36,17 @@
 typedef unsigned long long u64;
 
 #define DEV __device__ __forceinline__
+// cold paths are real calls: keeps them out of the hot loop's register allocation
+#define DEV_COLD __device__ __noinline__
 
 struct Wk {
-    // shared
-    uint32_t n_vars, n_orig;
-    const uint32_t* cl_off;
-    const int32_t* cl_lits;
-    const uint32_t* bin_off;
-    const int32_t* bin_lits;
-    // private
-    MsState* st;
-    uint8_t *val, *phase, *seen;
-    int32_t *level, *reason, *trail, *trail_lim, *vm_pos, *vm_order;
-    int2* wl;
-    uint32_t *w_base, *w_size, *w_cap;
-    int2* pool;
-    uint32_t *lc_off, *lc_lbd;
-    int32_t* lc_lits;
-    int32_t *learnt_buf, *toclear;
-    uint32_t *lvl_stamp, *remap;
-    int32_t *overflow, *assumps, *script;
-    uint32_t learnt_cap, learnt_lit_cap, pool_cap, vm_cap;
+    char* slab;                // this worker's private slab; arrays are at slab + L.<field>
     // LDS
     volatile int32_t* ring;
     volatile uint32_t* claim;
     volatile uint32_t* ov_cnt;
     volatile uint32_t* hist;   // 64 words, reduce_db
+    volatile uint32_t* lval;   // packed assignment, 2 bits per variable (LV variants)
     // hot uniform scalars
     int lane;
     int trail_n, qhead, n_levels, ring_lo;
@@ -64,12 +54,18 @@ struct Wk {
     uint32_t n_learnts, lc_lits_n, pool_top;
     int status;
     uint32_t lvl_stamp_ctr;
-    // conflict
-    int confl_kind, confl_cref, confl_a, confl_b;
-    // counters
-    u64 c_props, c_watch, c_move, c_enq, c_dec;
+    int max_groups;
+    // conflict: kind 1 long (cref), 2 binary (a,b), 3 ternary (a,b,c)
+    int confl_kind, confl_cref, confl_a, confl_b, confl_c;
+    // per-slice counters (flushed into the 64-bit totals of MsState at slice end)
+    uint32_t c_props, c_watch, c_move, c_enq, c_dec, c_steps, c_redo;
     uint32_t c_cl_lit;  // per lane
 };
+
+// Arrays are addressed through the kernel arguments (scalar registers / scalar loads), not through
+// pointers held per worker: `sh` = shared immutable CSRs, `L` = offsets inside the private slab.
+#define WK_PTR(T, w, L, field) ((T*)((w).slab + (L).field))
+#define WKA(T, field) ((T*)(w.slab + L.field))
 
 DEV u64 ballot(bool p) { return __ballot(p); }
 DEV int popc64(u64 m) { return __popcll(m); }
@@ -78,7 +74,7 @@ DEV u64 lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 DEV int bcast(int v, int src) { return __shfl(v, src, 64); }
 DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // Compiler-level ordering between lanes of the same wave (no instruction: memory
-// operations of one wave are issued in order; see DESIGN.md "intra-wave ordering").
+// operations of one wave are issued and performed in order; DESIGN.md "intra-wave ordering").
 DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 DEV void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -94,257 +90,334 @@ DEV u64 wave_sum_u32(uint32_t v) {
     return s;
 }
 
-DEV int lit_value(const Wk& w, int lit) { return (int)w.val[lit >> 1] ^ (lit & 1); }  // 0 T, 1 F, >=2 U
+// ---- assignment ------------------------------------------------------------------
+template <bool LV>
+DEV int lit_value(const Wk& w, const MsShared& sh, const MsLayout& L, int lit) {  // MS_VAL_TRUE / FALSE / UNDEF
+    const int v = lit >> 1;
+    uint32_t x;
+    if (LV) x = (w.lval[v >> 4] >> ((v & 15) * 2)) & 3u;
+    else x = WKA(uint8_t, val)[v];
+    return (x & 2u) ? (int)((x ^ (uint32_t)lit) & 1u) : MS_VAL_UNDEF;
+}
+template <bool LV>
+DEV void asg_set(Wk& w, const MsShared& sh, const MsLayout& L, int lit) {  // variable currently unassigned
+    const int v = lit >> 1;
+    if (LV) atomicOr((uint32_t*)&w.lval[v >> 4], (2u | (uint32_t)(lit & 1)) << ((v & 15) * 2));
+    else WKA(uint8_t, val)[v] = (uint8_t)(2 | (lit & 1));
+}
+template <bool LV>
+DEV void asg_clear(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
+    if (LV) atomicAnd((uint32_t*)&w.lval[v >> 4], ~(3u << ((v & 15) * 2)));
+    else WKA(uint8_t, val)[v] = MS_ASG_UNDEF;
+}
 
-DEV void clause_range(const Wk& w, int c, const int32_t*& lits, int& size) {
-    if ((uint32_t)c < w.n_orig) {
-        uint32_t o0 = w.cl_off[c], o1 = w.cl_off[c + 1];
-        lits = w.cl_lits + o0;
+DEV void clause_range(const Wk& w, const MsShared& sh, const MsLayout& L, int c, const int32_t*& lits, int& size) {
+    if ((uint32_t)c < sh.n_orig) {
+        uint32_t o0 = sh.cl_off[c], o1 = sh.cl_off[c + 1];
+        lits = sh.cl_lits + o0;
         size = (int)(o1 - o0);
     } else {
-        uint32_t k = (uint32_t)c - w.n_orig;
-        uint32_t o0 = w.lc_off[k], o1 = w.lc_off[k + 1];
-        lits = w.lc_lits + o0;
+        uint32_t k = (uint32_t)c - sh.n_orig;
+        const uint32_t* lc_off = WK_PTR(uint32_t, w, L, lc_off);
+        uint32_t o0 = lc_off[k], o1 = lc_off[k + 1];
+        lits = WK_PTR(int32_t, w, L, lc_lits) + o0;
         size = (int)(o1 - o0);
     }
 }
 
 // ---- trail -------------------------------------------------------------
-DEV void ring_note_growth(Wk& w) {
+DEV void ring_note_growth(Wk& w, const MsShared& sh, const MsLayout& L) {
     if (w.trail_n - w.ring_lo > MS_LDS_RING) w.ring_lo = w.trail_n - MS_LDS_RING;
 }
 
 // all lanes call with identical arguments
-DEV void enqueue_uniform(Wk& w, int lit, int reason) {
+template <bool LV>
+DEV void enqueue_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int lit, int reason) {
     wave_fence();  // every lane has finished reading the old assignment
     if (w.lane == 0) {
         int v = lit >> 1;
-        w.val[v] = (uint8_t)(lit & 1);
-        w.level[v] = w.n_levels;
-        w.reason[v] = reason;
-        w.trail[w.trail_n] = lit;
+        asg_set<LV>(w, sh, L, lit);
+        WKA(int32_t, level)[v] = w.n_levels;
+        WKA(int32_t, reason)[v] = reason;
+        WKA(int32_t, trail)[w.trail_n] = lit;
         w.ring[w.trail_n & (MS_LDS_RING - 1)] = lit;
     }
     w.trail_n++;
-    ring_note_growth(w);
-    wave_fence();
+    ring_note_growth(w, sh, L);
+    lds_fence();
 }
 
 // Lanes with `want` each imply literal q with reason `reason` (a cref, or a
-// binary reason code).  Several lanes may imply the same literal (keep one) or
-// complementary literals (conflict).  One LDS claim per variable decides.
-DEV void commit_implications(Wk& w, bool want, int q, int reason) {
+// binary / ternary reason code).  Several lanes may imply the same literal (keep
+// one) or complementary literals (conflict).  One LDS claim per variable decides.
+// A lane whose implication turned out to be falsified reports it through `lost`.
+template <bool LV>
+DEV void commit_implications(Wk& w, const MsShared& sh, const MsLayout& L, bool want, int q, int reason, bool& lost) {
+    lost = false;
     u64 m = ballot(want);
     if (m == 0) return;
     if ((m & (m - 1)) == 0) {  // single implication: no arbitration needed
         if (want) {
             int v = q >> 1;
-            w.val[v] = (uint8_t)(q & 1);
-            w.level[v] = w.n_levels;
-            w.reason[v] = reason;
-            w.trail[w.trail_n] = q;
+            asg_set<LV>(w, sh, L, q);
+            WKA(int32_t, level)[v] = w.n_levels;
+            WKA(int32_t, reason)[v] = reason;
+            WKA(int32_t, trail)[w.trail_n] = q;
             w.ring[w.trail_n & (MS_LDS_RING - 1)] = q;
         }
         w.trail_n++;
         w.c_enq++;
-        ring_note_growth(w);
-        wave_fence();
+        ring_note_growth(w, sh, L);
+        lds_fence();
         return;
     }
     const uint32_t slot = (((uint32_t)(q >> 1) * 2654435761u) >> 20) & (MS_CLAIM_SLOTS - 1);
     while (m) {
         if (want) w.claim[slot] = ((uint32_t)q << 6) | (uint32_t)w.lane;
         lds_fence();
-        bool won = false, cf = false;
+        bool won = false;
         if (want) {
             uint32_t c = w.claim[slot];
             int cq = (int)(c >> 6), cl = (int)(c & 63);
             if (cl == w.lane) { won = true; want = false; }
-            else if (cq == q) want = false;                    // same literal implied twice
-            else if (cq == (q ^ 1)) { cf = true; want = false; }  // complementary: my clause is now falsified
+            else if (cq == q) want = false;                      // same literal implied twice
+            else if (cq == (q ^ 1)) { lost = true; want = false; }  // complementary: my clause is now falsified
         }
         u64 wm = ballot(won);
         if (won) {
             int v = q >> 1;
             int t = w.trail_n + popc64(wm & lanemask_lt(w.lane));
-            w.val[v] = (uint8_t)(q & 1);
-            w.level[v] = w.n_levels;
-            w.reason[v] = reason;
-            w.trail[t] = q;
+            asg_set<LV>(w, sh, L, q);
+            WKA(int32_t, level)[v] = w.n_levels;
+            WKA(int32_t, reason)[v] = reason;
+            WKA(int32_t, trail)[t] = q;
             w.ring[t & (MS_LDS_RING - 1)] = q;
         }
         int nw = popc64(wm);
         w.trail_n += nw;
-        w.c_enq += (u64)nw;
-        ring_note_growth(w);
-        u64 cm = ballot(cf);
-        if (cm && !w.confl_kind) {
-            int f = first_lane(cm);
-            int r = bcast(reason, f), qf = bcast(q, f);
-            if (MS_IS_BIN_REASON(r)) { w.confl_kind = 2; w.confl_a = MS_BIN_REASON_LIT(r); w.confl_b = qf; }
-            else { w.confl_kind = 1; w.confl_cref = r; }
-        }
+        w.c_enq += (uint32_t)nw;
+        ring_note_growth(w, sh, L);
         lds_fence();
         m = ballot(want);
     }
-    wave_fence();
 }
 
 // ---- watch lists -------------------------------------------------------
 // Append (cref, blocker) to the list of literal t (uniform call, rare path:
 // learnt clause attach and overflow repair).  Grows the list from the bump pool.
-DEV bool list_push_uniform(Wk& w, int t, int cref, int blocker) {
-    uint32_t s = w.w_size[t], cap = w.w_cap[t];
-    s = (uint32_t)uni((int)s);
-    cap = (uint32_t)uni((int)cap);
+DEV bool list_push_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int t, int cref, int blocker) {
+    uint32_t s = (uint32_t)uni((int)WKA(uint32_t, w_size)[t]);
+    uint32_t cap = (uint32_t)uni((int)WKA(uint32_t, w_cap)[t]);
     if (s > cap) s = cap;  // overshoot left by failed atomic pushes
-    uint32_t base = (uint32_t)uni((int)w.w_base[t]);
+    uint32_t base = (uint32_t)uni((int)WKA(uint32_t, w_base)[t]);
     if (s == cap) {
         uint32_t ncap = cap < 4 ? 8 : cap * 2;
-        if (w.pool_top + ncap > w.pool_cap) { w.status = MS_ST_ERR_POOL; return false; }
+        if (w.pool_top + ncap > L.pool_cap) { w.status = MS_ST_ERR_POOL; return false; }
         uint32_t nb = w.pool_top;
         w.pool_top += ncap;
-        for (uint32_t i = (uint32_t)w.lane; i < s; i += MS_WAVE) w.pool[nb + i] = w.pool[base + i];
-        if (w.lane == 0) { w.w_base[t] = nb; w.w_cap[t] = ncap; }
+        for (uint32_t i = (uint32_t)w.lane; i < s; i += MS_WAVE) WKA(int2, pool)[nb + i] = WKA(int2, pool)[base + i];
+        if (w.lane == 0) { WKA(uint32_t, w_base)[t] = nb; WKA(uint32_t, w_cap)[t] = ncap; }
         base = nb;
     }
-    if (w.lane == 0) { w.pool[base + s] = make_int2(cref, blocker); w.w_size[t] = s + 1; }
+    if (w.lane == 0) { WKA(int2, pool)[base + s] = make_int2(cref, blocker); WKA(uint32_t, w_size)[t] = s + 1; }
     wave_fence();
     return true;
 }
 
-DEV void repair_overflow(Wk& w) {
-    uint32_t n = *w.ov_cnt;
-    n = (uint32_t)uni((int)n);
+DEV void repair_overflow(Wk& w, const MsShared& sh, const MsLayout& L) {
+    uint32_t n = (uint32_t)uni((int)*w.ov_cnt);
     if (n == 0) return;
     wave_fence();
+    const int32_t* ov = WK_PTR(int32_t, w, L, overflow);
     for (uint32_t e = 0; e < n && w.status == MS_ST_RUNNING; e++) {
-        int t = uni(w.overflow[3 * e]), c = uni(w.overflow[3 * e + 1]), b = uni(w.overflow[3 * e + 2]);
-        list_push_uniform(w, t, c, b);
+        int t = uni(ov[3 * e]), c = uni(ov[3 * e + 1]), b = uni(ov[3 * e + 2]);
+        list_push_uniform(w, sh, L, t, c, b);
     }
     if (w.lane == 0) *w.ov_cnt = 0;
     lds_fence();
 }
 
 // Unit propagation to fixpoint.  Returns true on conflict (w.confl_*).
-DEV bool propagate(Wk& w) {
+template <bool LV>
+DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
     w.confl_kind = 0;
-    while (w.qhead < w.trail_n) {
-        const int idx = w.qhead++;
-        int p = (idx >= w.ring_lo) ? w.ring[idx & (MS_LDS_RING - 1)] : w.trail[idx];
-        p = uni(p);
-        w.c_props++;
+    while (w.qhead < w.trail_n && w.status == MS_ST_RUNNING) {
+        // ---- split the wave into G groups of S lanes, one queue literal per group
+        const int qlen = w.trail_n - w.qhead;
+        int lg = qlen >= 8 ? 3 : (qlen >= 4 ? 2 : (qlen >= 2 ? 1 : 0));
+        if ((1 << lg) > w.max_groups) lg = w.max_groups >= 4 ? 2 : (w.max_groups >= 2 ? 1 : 0);
+        const int G = 1 << lg, S = MS_WAVE >> lg;
+        const int g = w.lane >> (6 - lg), sl = w.lane & (S - 1);
+        const u64 gmask = (S == MS_WAVE ? ~0ull : ((1ull << S) - 1ull)) << (g * S);
+        const int qbase = w.qhead;
+        const int idx = qbase + g;
+        const int p = (idx >= w.ring_lo) ? w.ring[idx & (MS_LDS_RING - 1)] : WKA(int32_t, trail)[idx];
         const int fl = p ^ 1;
-        // ---- binary clauses: static CSR shared by all workers -------------
-        {
-            const uint32_t b0 = w.bin_off[p], b1 = w.bin_off[p + 1];
-            for (uint32_t base = b0; base < b1; base += MS_WAVE) {
-                uint32_t i = base + (uint32_t)w.lane;
-                bool act = i < b1;
-                int q = act ? w.bin_lits[i] : 0;
-                int vq = act ? lit_value(w, q) : 0;
-                w.c_watch += (u64)popc64(ballot(act));
-                u64 cm = ballot(act && vq == MS_VAL_FALSE);
-                if (cm) {
-                    w.confl_kind = 2;
-                    w.confl_a = fl;
-                    w.confl_b = bcast(q, first_lane(cm));
-                    w.qhead = w.trail_n;
-                    return true;
-                }
-                commit_implications(w, act && vq >= MS_VAL_UNDEF, q, MS_REASON_BIN(fl));
-                if (w.confl_kind) { w.qhead = w.trail_n; return true; }
+        const uint32_t b0 = sh.bin_off[p], b1 = sh.bin_off[p + 1];
+        const uint32_t t0 = sh.tern_off[p], t1 = sh.tern_off[p + 1];
+        const uint32_t wb = WKA(uint32_t, w_base)[p];
+        const int n = (int)WKA(uint32_t, w_size)[p];
+        w.qhead += G;
+        w.c_props += (uint32_t)G;
+        w.c_steps++;
+        bool lost;
+        // the false literals of all groups of this step (uniform registers), for the clash test below
+        int bf[MS_MAX_GROUPS];
+#pragma unroll
+        for (int gg = 0; gg < MS_MAX_GROUPS; gg++) bf[gg] = gg < G ? __shfl(fl, gg * S, 64) : -1;
+        // ---- binary implications ------------------------------------------
+        for (uint32_t it = 0; ballot(b0 + it * S < b1) != 0; it++) {
+            const uint32_t i = b0 + it * S + (uint32_t)sl;
+            const bool act = i < b1;
+            const int q = act ? sh.bin_lits[i] : 0;
+            const int vq = act ? lit_value<LV>(w, sh, L, q) : MS_VAL_TRUE;
+            w.c_watch += (uint32_t)popc64(ballot(act));
+            commit_implications<LV>(w, sh, L, vq == MS_VAL_UNDEF, q, MS_REASON_BIN(fl), lost);
+            const u64 cm = ballot(vq == MS_VAL_FALSE || lost);
+            if (cm) {
+                const int f = first_lane(cm);
+                w.confl_kind = 2;
+                w.confl_a = bcast(fl, f);
+                w.confl_b = bcast(q, f);
+                w.qhead = w.trail_n;
+                return true;
             }
         }
-        // ---- long clauses: two watched literals -----------------------------
-        const uint32_t wb = (uint32_t)uni((int)w.w_base[p]);
-        const int n = uni((int)w.w_size[p]);
-        int j = 0;
-        int i0 = 0;
-        for (; i0 < n; i0 += MS_WAVE) {
-            const int i = i0 + w.lane;
+        // ---- ternary clauses: literal pairs, shared and read-only ---------
+        for (uint32_t it = 0; ballot(t0 + it * S < t1) != 0; it++) {
+            const uint32_t i = t0 + it * S + (uint32_t)sl;
+            const bool act = i < t1;
+            const int2 pr = act ? ((const int2*)sh.tern_pairs)[i] : make_int2(0, 0);
+            const int vb = act ? lit_value<LV>(w, sh, L, pr.x) : MS_VAL_TRUE;
+            const int vc = act ? lit_value<LV>(w, sh, L, pr.y) : MS_VAL_TRUE;
+            w.c_watch += (uint32_t)popc64(ballot(act));
+            const bool sat = vb == MS_VAL_TRUE || vc == MS_VAL_TRUE;
+            bool cf = !sat && vb == MS_VAL_FALSE && vc == MS_VAL_FALSE;
+            const bool want = !sat && !cf && (vb == MS_VAL_FALSE || vc == MS_VAL_FALSE);
+            const int imp = vb == MS_VAL_FALSE ? pr.y : pr.x;
+            commit_implications<LV>(w, sh, L, want, imp, MS_REASON_TERN(i), lost);
+            const u64 cm = ballot(cf || lost);
+            if (cm) {
+                const int f = first_lane(cm);
+                w.confl_kind = 3;
+                w.confl_a = bcast(fl, f);
+                w.confl_b = bcast(pr.x, f);
+                w.confl_c = bcast(pr.y, f);
+                w.qhead = w.trail_n;
+                return true;
+            }
+        }
+        // ---- long + learnt clauses: two watched literals ------------------
+        int j = 0;          // kept watchers of my group's list so far
+        int done = 0;       // list entries of my group's list already visited
+        int defer_g = MS_MAX_GROUPS;
+        for (int it = 0; ballot(it * S < n) != 0; it++) {
+            const int i = it * S + sl;
             const bool act = i < n;
-            int2 wt = act ? w.pool[wb + i] : make_int2(0, 0);
-            bool keep = act, want = false, cf = false;
+            int2 wt = act ? WKA(int2, pool)[wb + i] : make_int2(-1, 0);
+            const bool live = act && wt.x >= 0;       // cref < 0: tombstone left by an interrupted pass
+            bool keep = live, want = false, cf = false, deferred = false;
             int imp = 0;
-            if (act && lit_value(w, wt.y) != MS_VAL_TRUE) {
+            if (live && lit_value<LV>(w, sh, L, wt.y) != MS_VAL_TRUE) {
                 const int c = wt.x;
-                const int2 ww = w.wl[c];
+                const int2 ww = WKA(int2, wl)[c];
                 const int other = (ww.x == fl) ? ww.y : ww.x;
+                const int vo = lit_value<LV>(w, sh, L, other);
                 uint32_t nl = 2;
-                const int bl = wt.y;
-                wt.y = other;
-                if (other == bl || lit_value(w, other) != MS_VAL_TRUE) {
-                    const int32_t* cl;
-                    int size;
-                    clause_range(w, c, cl, size);
-                    int r = -1;
-                    for (int k = 0; k < size; k++) {
-                        int l = cl[k];
-                        if (l == fl || l == other) continue;
-                        nl++;
-                        if (lit_value(w, l) != MS_VAL_FALSE) { r = l; break; }
+                if (vo == MS_VAL_TRUE) wt.y = other;
+                else {
+                    // both watches false and the other one is being propagated by another group in
+                    // this very step: the lower group handles the clause, the higher one re-queues
+                    bool other_lower = false;
+                    if (vo == MS_VAL_FALSE) {
+#pragma unroll
+                        for (int gg = 0; gg < MS_MAX_GROUPS; gg++) other_lower = other_lower || (gg < g && bf[gg] == other);
                     }
-                    if (r >= 0) {
-                        w.wl[c] = make_int2(other, r);
-                        const int t = r ^ 1;
-                        uint32_t pos = atomicAdd(&w.w_size[t], 1u);
-                        if (pos < w.w_cap[t]) w.pool[w.w_base[t] + pos] = wt;
-                        else {
-                            uint32_t o = atomicAdd((uint32_t*)w.ov_cnt, 1u);
-                            w.overflow[3 * o] = t;
-                            w.overflow[3 * o + 1] = c;
-                            w.overflow[3 * o + 2] = other;
+                    if (other_lower) deferred = true;
+                    else {
+                        wt.y = other;
+                        const int32_t* cl;
+                        int size;
+                        clause_range(w, sh, L, c, cl, size);
+                        int r = -1;
+                        for (int k = 0; k < size; k++) {
+                            int l = cl[k];
+                            if (l == fl || l == other) continue;
+                            nl++;
+                            if (lit_value<LV>(w, sh, L, l) != MS_VAL_FALSE) { r = l; break; }
                         }
-                        keep = false;
-                    } else if (lit_value(w, other) == MS_VAL_FALSE) cf = true;
-                    else { want = true; imp = other; }
+                        if (r >= 0) {
+                            WKA(int2, wl)[c] = make_int2(other, r);
+                            const int t = r ^ 1;
+                            uint32_t pos = atomicAdd(&WKA(uint32_t, w_size)[t], 1u);
+                            if (pos < WKA(uint32_t, w_cap)[t]) WKA(int2, pool)[WKA(uint32_t, w_base)[t] + pos] = wt;
+                            else {
+                                uint32_t o = atomicAdd((uint32_t*)w.ov_cnt, 1u);
+                                int32_t* ov = WK_PTR(int32_t, w, L, overflow);
+                                ov[3 * o] = t;
+                                ov[3 * o + 1] = c;
+                                ov[3 * o + 2] = other;
+                            }
+                            keep = false;
+                        } else if (vo == MS_VAL_FALSE) cf = true;
+                        else { want = true; imp = other; }
+                    }
                 }
                 w.c_cl_lit += nl;
             }
-            w.c_watch += (u64)popc64(ballot(act));
-            w.c_move += (u64)popc64(ballot(act && !keep));
-            // compaction of kept watchers (dest index <= source index)
-            u64 km = ballot(keep);
-            if (keep) w.pool[wb + j + popc64(km & lanemask_lt(w.lane))] = wt;
-            j += popc64(km);
-            repair_overflow(w);
-            u64 cm = ballot(cf);
+            w.c_watch += (uint32_t)popc64(ballot(live));
+            w.c_move += (uint32_t)popc64(ballot(live && !keep));
+            // in-place compaction of the kept watchers of each group's list (dest <= source)
+            const u64 km = ballot(keep);
+            wave_fence();
+            if (keep) WKA(int2, pool)[wb + j + popc64(km & gmask & lanemask_lt(w.lane))] = wt;
+            j += popc64(km & gmask);
+            done = min(n, (it + 1) * S);
+            const u64 dm = ballot(deferred);
+            if (dm) defer_g = min(defer_g, first_lane(dm) >> (6 - lg));
+            repair_overflow(w, sh, L);
+            commit_implications<LV>(w, sh, L, want, imp, wt.x, lost);
+            const u64 cm = ballot(cf || lost);
             if (cm) {
                 w.confl_kind = 1;
                 w.confl_cref = bcast(wt.x, first_lane(cm));
-            } else {
-                commit_implications(w, want, imp, wt.x);
+                break;
             }
-            if (w.confl_kind || w.status != MS_ST_RUNNING) { i0 += MS_WAVE; break; }
+            if (w.status != MS_ST_RUNNING) break;
         }
-        // conflict: copy the unvisited tail down
-        for (; i0 < n; i0 += MS_WAVE) {
-            const int i = i0 + w.lane;
-            if (i < n) {
-                int2 wt = w.pool[wb + i];
-                w.pool[wb + j + w.lane] = wt;
-            }
-            j += min(MS_WAVE, n - i0);
-        }
-        if (w.lane == 0) w.w_size[p] = (uint32_t)j;
+        // close each group's list: fully visited -> new size; interrupted -> tombstone the gap
+        // between the compacted prefix and the first unvisited entry
         wave_fence();
-        if (w.confl_kind || w.status != MS_ST_RUNNING) { w.qhead = w.trail_n; return w.confl_kind != 0; }
+        if (done == n) {
+            if (sl == 0 && n > 0) WKA(uint32_t, w_size)[p] = (uint32_t)j;
+        } else {
+            for (int x = j + sl; x < done; x += S) WKA(int2, pool)[wb + x] = make_int2(-1, 0);
+        }
+        wave_fence();
+        if (w.confl_kind) { w.qhead = w.trail_n; return true; }
+        if (defer_g < G) {  // re-queue the deferred group's literal and everything after it
+            w.qhead = qbase + defer_g;
+            w.c_props -= (uint32_t)(G - defer_g);
+            w.c_redo += (uint32_t)(G - defer_g);
+        }
     }
     return false;
 }
 
 // ---- backtracking --------------------------------------------------------
-DEV void cancel_until(Wk& w, int lvl) {
+template <bool LV>
+DEV void cancel_until(Wk& w, const MsShared& sh, const MsLayout& L, int lvl) {
     if (w.n_levels <= lvl) return;
-    const int lim = uni(w.trail_lim[lvl]);
+    const int lim = uni(WK_PTR(int32_t, w, L, trail_lim)[lvl]);
+    uint8_t* phase = WK_PTR(uint8_t, w, L, phase);
+    const int32_t* vm_pos = WK_PTR(int32_t, w, L, vm_pos);
     int maxpos = -1;
     for (int i = lim + w.lane; i < w.trail_n; i += MS_WAVE) {
-        int l = w.trail[i];
+        int l = WKA(int32_t, trail)[i];
         int v = l >> 1;
-        w.val[v] = MS_VAL_UNDEF;
-        w.phase[v] = (uint8_t)(l & 1);
-        maxpos = max(maxpos, w.vm_pos[v]);
+        asg_clear<LV>(w, sh, L, v);
+        phase[v] = (uint8_t)(l & 1);
+        maxpos = max(maxpos, vm_pos[v]);
     }
     maxpos = wave_max(maxpos);
     if (maxpos > w.vm_search) w.vm_search = maxpos;
@@ -352,11 +425,11 @@ DEV void cancel_until(Wk& w, int lvl) {
     w.qhead = lim;
     w.n_levels = lvl;
     if (w.ring_lo > lim) w.ring_lo = lim;
-    wave_fence();
+    lds_fence();
 }
 
-DEV void new_decision_level(Wk& w) {
-    if (w.lane == 0) w.trail_lim[w.n_levels] = w.trail_n;
+DEV void new_decision_level(Wk& w, const MsShared& sh, const MsLayout& L) {
+    if (w.lane == 0) WK_PTR(int32_t, w, L, trail_lim)[w.n_levels] = w.trail_n;
     w.n_levels++;
 }
 
@@ -364,18 +437,21 @@ DEV void new_decision_level(Wk& w) {
 // vm_order[0..vm_end) holds variables; the entry of v is live iff vm_pos[v] is its
 // index.  Later index = more recently bumped.  vm_search: every live entry above
 // it is assigned.
-DEV void vm_compact(Wk& w) {
+DEV_COLD void vm_compact(Wk& w, const MsShared& sh, const MsLayout& L) {
+    int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
+    int32_t* vm_pos = WK_PTR(int32_t, w, L, vm_pos);
     int j = 0;
     for (int i0 = 0; i0 < w.vm_end; i0 += MS_WAVE) {
         int i = i0 + w.lane;
         int v = -1;
         bool live = false;
-        if (i < w.vm_end) { v = w.vm_order[i]; live = w.vm_pos[v] == i; }
+        if (i < w.vm_end) { v = vm_order[i]; live = vm_pos[v] == i; }
         u64 m = ballot(live);
+        wave_fence();
         if (live) {
             int d = j + popc64(m & lanemask_lt(w.lane));
-            w.vm_order[d] = v;
-            w.vm_pos[v] = d;
+            vm_order[d] = v;
+            vm_pos[v] = d;
         }
         j += popc64(m);
         wave_fence();
@@ -384,15 +460,33 @@ DEV void vm_compact(Wk& w) {
     w.vm_search = j - 1;
 }
 
-DEV int pick_branch_var(Wk& w) {
+// Cold-path calls: the callee works on private copies of the worker context and the
+// layout, so the hot loop's copy never has its address taken and stays in registers.
+#define WK_COPY_BACK(dst, src)                                                                        \
+    do {                                                                                              \
+        (dst).n_learnts = (src).n_learnts; (dst).lc_lits_n = (src).lc_lits_n; (dst).pool_top = (src).pool_top; \
+        (dst).status = (src).status; (dst).vm_end = (src).vm_end; (dst).vm_search = (src).vm_search;           \
+    } while (0)
+DEV void vm_compact_call(Wk& w, const MsShared& sh, const MsLayout& L) {
+    Wk t = w;
+    MsShared sc = sh;
+    MsLayout lc = L;
+    vm_compact(t, sc, lc);
+    WK_COPY_BACK(w, t);
+}
+
+template <bool LV>
+DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
+    const int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
+    const int32_t* vm_pos = WK_PTR(int32_t, w, L, vm_pos);
     for (;;) {
         if (w.vm_search < 0) return -1;
         int idx = w.vm_search - w.lane;
         int v = -1;
         bool ok = false;
         if (idx >= 0) {
-            v = w.vm_order[idx];
-            ok = w.vm_pos[v] == idx && w.val[v] == MS_VAL_UNDEF;
+            v = vm_order[idx];
+            ok = vm_pos[v] == idx && lit_value<LV>(w, sh, L, 2 * v) == MS_VAL_UNDEF;
         }
         u64 m = ballot(ok);
         if (m) {
@@ -407,52 +501,57 @@ DEV int pick_branch_var(Wk& w) {
 // ---- conflict analysis (first UIP) -----------------------------------------
 struct Learnt { int n, bt_level; uint32_t lbd; };
 
-DEV void analyze_visit(Wk& w, bool act, int q, int dl, int& path_c, int& n_out, int& n_clear) {
+DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, uint8_t* seen, int32_t* toclear, int32_t* learnt_buf, bool act, int q, int dl,
+                       int& path_c, int& n_out, int& n_clear) {
     int v = q >> 1;
     bool fresh = false, cur = false;
     if (act) {
-        int lv = w.level[v];
-        fresh = !w.seen[v] && lv > 0;
+        int lv = WKA(int32_t, level)[v];
+        fresh = !seen[v] && lv > 0;
         cur = fresh && lv >= dl;
     }
     u64 fm = ballot(fresh), cm = ballot(cur);
     u64 lm = fm & ~cm;
     if (fresh) {
-        w.seen[v] = 1;
-        w.toclear[n_clear + popc64(fm & lanemask_lt(w.lane))] = v;
-        if (!cur) w.learnt_buf[n_out + popc64(lm & lanemask_lt(w.lane))] = q;
+        seen[v] = 1;
+        toclear[n_clear + popc64(fm & lanemask_lt(w.lane))] = v;
+        if (!cur) learnt_buf[n_out + popc64(lm & lanemask_lt(w.lane))] = q;
     }
     n_clear += popc64(fm);
     n_out += popc64(lm);
     path_c += popc64(cm);
 }
 
-DEV Learnt analyze(Wk& w) {
+DEV_COLD Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
+    uint8_t* seen = WK_PTR(uint8_t, w, L, seen);
+    int32_t* toclear = WK_PTR(int32_t, w, L, toclear);
+    int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
+    uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
     int path_c = 0, p = -1, n_out = 1, n_clear = 0;
     int index = w.trail_n - 1;
     const int dl = w.n_levels;
-    int kind = w.confl_kind, cref = w.confl_cref, ba = w.confl_a, bb = w.confl_b;
+    int kind = w.confl_kind, cref = w.confl_cref, ba = w.confl_a, bb = w.confl_b, bc = w.confl_c;
     for (;;) {
         if (kind == 1) {
             const int32_t* cl;
             int size;
-            clause_range(w, cref, cl, size);
-            if ((uint32_t)cref >= w.n_orig && w.lane == 0) w.lc_lbd[cref - w.n_orig] |= 0x80000000u;  // used
+            clause_range(w, sh, L, cref, cl, size);
+            if ((uint32_t)cref >= sh.n_orig && w.lane == 0) lc_lbd[cref - sh.n_orig] |= 0x80000000u;  // used
             for (int k0 = 0; k0 < size; k0 += MS_WAVE) {
                 int k = k0 + w.lane;
                 int q = k < size ? cl[k] : 0;
-                analyze_visit(w, k < size && q != p, q, dl, path_c, n_out, n_clear);
+                analyze_visit(w, sh, L, seen, toclear, learnt_buf, k < size && q != p, q, dl, path_c, n_out, n_clear);
             }
         } else {
-            int q = w.lane == 0 ? ba : bb;
-            analyze_visit(w, w.lane < 2 && q != p, q, dl, path_c, n_out, n_clear);
+            int q = w.lane == 0 ? ba : (w.lane == 1 ? bb : bc);
+            analyze_visit(w, sh, L, seen, toclear, learnt_buf, w.lane < kind && q != p, q, dl, path_c, n_out, n_clear);
         }
         wave_fence();
         // walk the trail back to the most recent literal marked seen
         for (;;) {
             int i = index - w.lane;
-            int l = i >= 0 ? w.trail[i] : 0;
-            bool ok = i >= 0 && w.seen[l >> 1];
+            int l = i >= 0 ? WKA(int32_t, trail)[i] : 0;
+            bool ok = i >= 0 && seen[l >> 1];
             u64 m = ballot(ok);
             if (m) {
                 int f = first_lane(m);
@@ -465,43 +564,62 @@ DEV Learnt analyze(Wk& w) {
         }
         index--;
         const int v = p >> 1;
-        const int r = uni(w.reason[v]);
-        if (w.lane == 0) w.seen[v] = 0;
+        const int r = uni(WKA(int32_t, reason)[v]);
+        wave_fence();
+        if (w.lane == 0) seen[v] = 0;
         wave_fence();
         path_c--;
         if (path_c <= 0) break;
         if (r >= 0) { kind = 1; cref = r; }
+        else if (MS_IS_TERN_REASON(r)) {
+            const int e = MS_TERN_REASON_ENTRY(r);
+            const int2 pr = ((const int2*)sh.tern_pairs)[e];
+            kind = 3; ba = uni(sh.tern_owner[e]) ^ 1; bb = uni(pr.x); bc = uni(pr.y);
+        }
         else if (MS_IS_BIN_REASON(r)) { kind = 2; ba = p; bb = MS_BIN_REASON_LIT(r); }
         else { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
     }
-    if (w.lane == 0) w.learnt_buf[0] = p ^ 1;
+    wave_fence();
+    if (w.lane == 0) learnt_buf[0] = p ^ 1;
     wave_fence();
     // ---- local minimisation: drop a literal whose reason's other literals are all seen / level 0
     int j = 1;
     for (int i0 = 1; i0 < n_out; i0 += MS_WAVE) {
         int i = i0 + w.lane;
         bool act = i < n_out, keep = act;
-        int q = act ? w.learnt_buf[i] : 0;
+        int q = act ? learnt_buf[i] : 0;
         if (act) {
-            int r = w.reason[q >> 1];
+            int r = WKA(int32_t, reason)[q >> 1];
             if (r >= 0) {
                 const int32_t* cl;
                 int size;
-                clause_range(w, r, cl, size);
+                clause_range(w, sh, L, r, cl, size);
                 bool red = true;
                 for (int k = 0; k < size && red; k++) {
                     int l = cl[k];
                     if ((l >> 1) == (q >> 1)) continue;
-                    red = w.seen[l >> 1] || w.level[l >> 1] == 0;
+                    red = seen[l >> 1] || WKA(int32_t, level)[l >> 1] == 0;
+                }
+                keep = !red;
+            } else if (MS_IS_TERN_REASON(r)) {
+                const int e = MS_TERN_REASON_ENTRY(r);
+                const int2 pr = ((const int2*)sh.tern_pairs)[e];
+                const int l3[3] = {sh.tern_owner[e] ^ 1, pr.x, pr.y};
+                bool red = true;
+                for (int k = 0; k < 3; k++) {
+                    int l = l3[k];
+                    if ((l >> 1) == (q >> 1)) continue;
+                    red = red && (seen[l >> 1] || WKA(int32_t, level)[l >> 1] == 0);
                 }
                 keep = !red;
             } else if (MS_IS_BIN_REASON(r)) {
                 int l = MS_BIN_REASON_LIT(r);
-                keep = !(w.seen[l >> 1] || w.level[l >> 1] == 0);
+                keep = !(seen[l >> 1] || WKA(int32_t, level)[l >> 1] == 0);
             }
         }
         u64 km = ballot(keep);
-        if (keep) w.learnt_buf[j + popc64(km & lanemask_lt(w.lane))] = q;
+        wave_fence();
+        if (keep) learnt_buf[j + popc64(km & lanemask_lt(w.lane))] = q;
         j += popc64(km);
         wave_fence();
     }
@@ -511,7 +629,7 @@ DEV Learnt analyze(Wk& w) {
     if (n_out > 1) {
         int best = -1, best_i = 0x7fffffff;
         for (int i = 1 + w.lane; i < n_out; i += MS_WAVE) {
-            int lv = w.level[w.learnt_buf[i] >> 1];
+            int lv = WKA(int32_t, level)[learnt_buf[i] >> 1];
             if (lv > best) { best = lv; best_i = i; }
         }
         int mx = wave_max(best);
@@ -519,46 +637,61 @@ DEV Learnt analyze(Wk& w) {
         int mi = -wave_max(-cand);
         bt = mx;
         if (w.lane == 0 && mi != 1) {
-            int t = w.learnt_buf[mi];
-            w.learnt_buf[mi] = w.learnt_buf[1];
-            w.learnt_buf[1] = t;
+            int t = learnt_buf[mi];
+            learnt_buf[mi] = learnt_buf[1];
+            learnt_buf[1] = t;
         }
         wave_fence();
     }
     // ---- LBD: number of distinct decision levels
     uint32_t lbd = 0;
     {
+        uint32_t* lvl_stamp = WK_PTR(uint32_t, w, L, lvl_stamp);
         const uint32_t base = w.lvl_stamp_ctr;
         for (int i0 = 0; i0 < n_out; i0 += MS_WAVE) {
             int i = i0 + w.lane;
             bool act = i < n_out;
-            int lv = act ? w.level[w.learnt_buf[i] >> 1] : 0;
+            int lv = act ? WKA(int32_t, level)[learnt_buf[i] >> 1] : 0;
             uint32_t id = base + 1 + (uint32_t)i;
-            bool cand = act && w.lvl_stamp[lv] <= base;
-            if (cand) w.lvl_stamp[lv] = id;
+            bool cand = act && lvl_stamp[lv] <= base;
             wave_fence();
-            bool won = cand && w.lvl_stamp[lv] == id;
+            if (cand) lvl_stamp[lv] = id;
+            wave_fence();
+            bool won = cand && lvl_stamp[lv] == id;
             lbd += (uint32_t)popc64(ballot(won));
             wave_fence();
         }
         uint32_t nb = base + (uint32_t)n_out + 1;
         if (nb > 0xf0000000u) {  // stamp space exhausted: reset
-            for (uint32_t i = (uint32_t)w.lane; i < w.n_vars + 2; i += MS_WAVE) w.lvl_stamp[i] = 0;
+            for (uint32_t i = (uint32_t)w.lane; i < sh.n_vars + 2; i += MS_WAVE) lvl_stamp[i] = 0;
             nb = 0;
         }
         w.lvl_stamp_ctr = nb;
     }
     // ---- clear marks and bump the analysed variables to the front of the queue
-    if (w.vm_end + n_clear > (int)w.vm_cap) vm_compact(w);
-    for (int i = w.lane; i < n_clear; i += MS_WAVE) {
-        int v = w.toclear[i];
-        w.seen[v] = 0;
-        w.vm_order[w.vm_end + i] = v;
-        w.vm_pos[v] = w.vm_end + i;
+    if (w.vm_end + n_clear > (int)L.vm_cap) vm_compact(w, sh, L);
+    {
+        int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
+        int32_t* vm_pos = WK_PTR(int32_t, w, L, vm_pos);
+        for (int i = w.lane; i < n_clear; i += MS_WAVE) {
+            int v = toclear[i];
+            seen[v] = 0;
+            vm_order[w.vm_end + i] = v;
+            vm_pos[v] = w.vm_end + i;
+        }
     }
     w.vm_end += n_clear;
     wave_fence();
     return Learnt{n_out, bt, lbd};
+}
+
+DEV Learnt analyze_call(Wk& w, const MsShared& sh, const MsLayout& L) {
+    Wk t = w;
+    MsShared sc = sh;
+    MsLayout lc = L;
+    Learnt r = analyze(t, sc, lc);
+    w.status = t.status; w.vm_end = t.vm_end; w.vm_search = t.vm_search; w.lvl_stamp_ctr = t.lvl_stamp_ctr;
+    return r;
 }
 
 // ---- watch pool garbage collection ---------------------------------------------------
@@ -566,39 +699,40 @@ DEV Learnt analyze(Wk& w) {
 // hole behind.  The rebuild lays every list out again, densely, straight from the
 // per-clause watched-literal pairs (no read of the old pool): count, exclusive scan
 // over the 2*n_vars lists (wave prefix sums), fill.  Runs at a propagation fixpoint.
-DEV void rebuild_watches(Wk& w) {
-    const uint32_t nlist = 2 * w.n_vars;
-    const uint32_t ncl = w.n_orig + w.n_learnts;
-    for (uint32_t t = (uint32_t)w.lane; t < nlist; t += MS_WAVE) w.w_size[t] = 0;
+DEV_COLD void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
+    const uint32_t nlist = 2 * sh.n_vars;
+    const uint32_t ncl = sh.n_orig + w.n_learnts;
+    for (uint32_t t = (uint32_t)w.lane; t < nlist; t += MS_WAVE) WKA(uint32_t, w_size)[t] = 0;
     wave_fence();
     for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
-        int2 ww = w.wl[c];
-        atomicAdd(&w.w_size[ww.x ^ 1], 1u);
-        atomicAdd(&w.w_size[ww.y ^ 1], 1u);
+        int2 ww = WKA(int2, wl)[c];
+        atomicAdd(&WKA(uint32_t, w_size)[ww.x ^ 1], 1u);
+        atomicAdd(&WKA(uint32_t, w_size)[ww.y ^ 1], 1u);
     }
     wave_fence();
     uint32_t run = 0;
     for (uint32_t t0 = 0; t0 < nlist; t0 += MS_WAVE) {
         uint32_t t = t0 + (uint32_t)w.lane;
-        uint32_t sz = t < nlist ? w.w_size[t] : 0;
-        uint32_t cap = t < nlist ? sz + (sz >> 1) + 4 : 0;
+        uint32_t sz = t < nlist ? WKA(uint32_t, w_size)[t] : 0;
+        uint32_t cap = t < nlist ? sz + (sz >> 1) + 2 : 0;
         uint32_t incl = cap;
         for (int o = 1; o < MS_WAVE; o <<= 1) {
             uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64);
             if (w.lane >= o) incl += x;
         }
-        if (t < nlist) { w.w_base[t] = run + incl - cap; w.w_cap[t] = cap; w.w_size[t] = 0; }
+        wave_fence();
+        if (t < nlist) { WKA(uint32_t, w_base)[t] = run + incl - cap; WKA(uint32_t, w_cap)[t] = cap; WKA(uint32_t, w_size)[t] = 0; }
         run += (uint32_t)bcast((int)incl, 63);
     }
-    if (run > w.pool_cap) { w.status = MS_ST_ERR_POOL; return; }
+    if (run > L.pool_cap) { w.status = MS_ST_ERR_POOL; return; }
     w.pool_top = run;
     wave_fence();
     for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
-        int2 ww = w.wl[c];
-        uint32_t pa = atomicAdd(&w.w_size[ww.x ^ 1], 1u);
-        w.pool[w.w_base[ww.x ^ 1] + pa] = make_int2((int)c, ww.y);
-        uint32_t pb = atomicAdd(&w.w_size[ww.y ^ 1], 1u);
-        w.pool[w.w_base[ww.y ^ 1] + pb] = make_int2((int)c, ww.x);
+        int2 ww = WKA(int2, wl)[c];
+        uint32_t pa = atomicAdd(&WKA(uint32_t, w_size)[ww.x ^ 1], 1u);
+        WKA(int2, pool)[WKA(uint32_t, w_base)[ww.x ^ 1] + pa] = make_int2((int)c, ww.y);
+        uint32_t pb = atomicAdd(&WKA(uint32_t, w_size)[ww.y ^ 1], 1u);
+        WKA(int2, pool)[WKA(uint32_t, w_base)[ww.y ^ 1] + pb] = make_int2((int)c, ww.x);
     }
     wave_fence();
 }
@@ -607,12 +741,18 @@ DEV void rebuild_watches(Wk& w) {
 // Keep every clause with lbd <= 2, every locked clause and every clause used
 // since the last reduction with lbd <= 6; of the rest drop the worse half by an
 // LBD cut-off (histogram in LDS, no sort), breaking ties by age.
-DEV void reduce_db(Wk& w, volatile uint32_t* hist /* 64 LDS words */) {
+template <bool LV>
+DEV_COLD void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
+    volatile uint32_t* hist = w.hist;
+    uint32_t* lc_off = WK_PTR(uint32_t, w, L, lc_off);
+    uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
+    int32_t* lc_lits = WK_PTR(int32_t, w, L, lc_lits);
+    uint32_t* remap = WK_PTR(uint32_t, w, L, remap);
     const uint32_t n = w.n_learnts;
-    if (w.lane < 64) hist[w.lane] = 0;
+    hist[w.lane] = 0;
     lds_fence();
     for (uint32_t k = (uint32_t)w.lane; k < n; k += MS_WAVE) {
-        uint32_t l = w.lc_lbd[k] & 0x7fffffffu;
+        uint32_t l = lc_lbd[k] & 0x7fffffffu;
         atomicAdd((uint32_t*)&hist[l > 63 ? 63 : l], 1u);
     }
     lds_fence();
@@ -636,15 +776,15 @@ DEV void reduce_db(Wk& w, volatile uint32_t* hist /* 64 LDS words */) {
         int2 ww = make_int2(0, 0);
         bool at_cut = false;
         if (act) {
-            uint32_t raw = w.lc_lbd[k];
+            uint32_t raw = lc_lbd[k];
             lb = raw & 0x7fffffffu;
             bool used = raw >> 31;
-            o0 = w.lc_off[k];
-            o1 = w.lc_off[k + 1];
-            ww = w.wl[w.n_orig + k];
-            int cref = (int)(w.n_orig + k);
-            bool locked = (lit_value(w, ww.x) == MS_VAL_TRUE && w.reason[ww.x >> 1] == cref) ||
-                          (lit_value(w, ww.y) == MS_VAL_TRUE && w.reason[ww.y >> 1] == cref);
+            o0 = lc_off[k];
+            o1 = lc_off[k + 1];
+            ww = WKA(int2, wl)[sh.n_orig + k];
+            int cref = (int)(sh.n_orig + k);
+            bool locked = (lit_value<LV>(w, sh, L, ww.x) == MS_VAL_TRUE && WKA(int32_t, reason)[ww.x >> 1] == cref) ||
+                          (lit_value<LV>(w, sh, L, ww.y) == MS_VAL_TRUE && WKA(int32_t, reason)[ww.y >> 1] == cref);
             bool protect = locked || lb <= 2 || (used && lb <= 6) || (o1 - o0) <= 2;
             if (!protect) {
                 if (lb > cut) del = true;
@@ -669,107 +809,133 @@ DEV void reduce_db(Wk& w, volatile uint32_t* hist /* 64 LDS words */) {
         uint32_t total = (uint32_t)bcast((int)pre, 63);
         pre -= len;
         uint32_t nkk = nk + (uint32_t)popc64(km & lanemask_lt(w.lane));
-        if (act) w.remap[k] = keep ? nkk : 0xffffffffu;
+        if (act) remap[k] = keep ? nkk : 0xffffffffu;
         wave_fence();
         // move literals (dest <= source, clause by clause inside the chunk in lane order)
         for (int src = 0; src < MS_WAVE; src++) {
             if (!((km >> src) & 1)) continue;
-            uint32_t so = (uint32_t)bcast((int)o0, src), sl = (uint32_t)bcast((int)len, src);
+            uint32_t so = (uint32_t)bcast((int)o0, src), slen = (uint32_t)bcast((int)len, src);
             uint32_t dd = nlits + (uint32_t)bcast((int)pre, src);
             if (dd != so)
-                for (uint32_t t = 0; t < sl; t += MS_WAVE) {
+                for (uint32_t t = 0; t < slen; t += MS_WAVE) {
                     uint32_t x = t + (uint32_t)w.lane;
-                    int lv = x < sl ? w.lc_lits[so + x] : 0;
+                    int lv = x < slen ? lc_lits[so + x] : 0;
                     wave_fence();
-                    if (x < sl) w.lc_lits[dd + x] = lv;
+                    if (x < slen) lc_lits[dd + x] = lv;
                     wave_fence();
                 }
         }
         if (keep) {
-            w.lc_off[nkk] = nlits + pre;
-            w.lc_lbd[nkk] = lb;  // clears the used bit
-            w.wl[w.n_orig + nkk] = ww;
+            lc_off[nkk] = nlits + pre;
+            lc_lbd[nkk] = lb;  // clears the used bit
+            WKA(int2, wl)[sh.n_orig + nkk] = ww;
         }
         nk += nkeep;
         nlits += total;
         wave_fence();
     }
-    if (w.lane == 0) w.lc_off[nk] = nlits;
+    if (w.lane == 0) lc_off[nk] = nlits;
     // pass 2: lay the watch lists out again without the deleted clauses (also collects pool garbage)
     w.n_learnts = nk;
     w.lc_lits_n = nlits;
     wave_fence();
-    rebuild_watches(w);
+    rebuild_watches(w, sh, L);
     // pass 3: reasons of assigned variables
     for (int i = w.lane; i < w.trail_n; i += MS_WAVE) {
-        int v = w.trail[i] >> 1;
-        int r = w.reason[v];
-        if (r >= 0 && (uint32_t)r >= w.n_orig) w.reason[v] = (int)(w.n_orig + w.remap[(uint32_t)r - w.n_orig]);
+        int v = WKA(int32_t, trail)[i] >> 1;
+        int r = WKA(int32_t, reason)[v];
+        if (r >= 0 && (uint32_t)r >= sh.n_orig) WKA(int32_t, reason)[v] = (int)(sh.n_orig + remap[(uint32_t)r - sh.n_orig]);
     }
-    w.n_learnts = nk;
-    w.lc_lits_n = nlits;
     wave_fence();
 }
 
+template <bool LV>
+DEV void reduce_db_call(Wk& w, const MsShared& sh, const MsLayout& L) {
+    Wk t = w;
+    MsShared sc = sh;
+    MsLayout lc = L;
+    reduce_db<LV>(t, sc, lc);
+    WK_COPY_BACK(w, t);
+}
+DEV void rebuild_watches_call(Wk& w, const MsShared& sh, const MsLayout& L) {
+    Wk t = w;
+    MsShared sc = sh;
+    MsLayout lc = L;
+    rebuild_watches(t, sc, lc);
+    WK_COPY_BACK(w, t);
+}
+
 // Store the clause in learnt_buf[0..n) and attach it.  Returns its cref (or -1).
-DEV int add_learnt(Wk& w, int n, uint32_t lbd) {
-    if (w.n_learnts >= w.learnt_cap || w.lc_lits_n + (uint32_t)n > w.learnt_lit_cap) {
-        reduce_db(w, w.hist);  // store full before the scheduled reduction: reduce now (state is consistent here)
-        if (w.n_learnts >= w.learnt_cap || w.lc_lits_n + (uint32_t)n > w.learnt_lit_cap) {
+template <bool LV>
+DEV int add_learnt(Wk& w, const MsShared& sh, const MsLayout& L, int n, uint32_t lbd) {
+    if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n > L.learnt_lit_cap) {
+        reduce_db_call<LV>(w, sh, L);  // store full before the scheduled reduction: reduce now (state is consistent here)
+        if (w.status != MS_ST_RUNNING) return -1;
+        if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n > L.learnt_lit_cap) {
             w.status = MS_ST_ERR_LEARNT;
             return -1;
         }
     }
+    const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
+    uint32_t* lc_off = WK_PTR(uint32_t, w, L, lc_off);
+    int32_t* lc_lits = WK_PTR(int32_t, w, L, lc_lits);
     const uint32_t k = w.n_learnts, o = w.lc_lits_n;
-    for (int i = w.lane; i < n; i += MS_WAVE) w.lc_lits[o + i] = w.learnt_buf[i];
-    const int l0 = uni(w.learnt_buf[0]), l1 = uni(w.learnt_buf[1]);
-    const int cref = (int)(w.n_orig + k);
+    for (int i = w.lane; i < n; i += MS_WAVE) lc_lits[o + i] = learnt_buf[i];
+    const int l0 = uni(learnt_buf[0]), l1 = uni(learnt_buf[1]);
+    const int cref = (int)(sh.n_orig + k);
     if (w.lane == 0) {
-        w.lc_off[k] = o;
-        w.lc_off[k + 1] = o + (uint32_t)n;
-        w.lc_lbd[k] = lbd;
-        w.wl[cref] = make_int2(l0, l1);
+        lc_off[k] = o;
+        lc_off[k + 1] = o + (uint32_t)n;
+        WK_PTR(uint32_t, w, L, lc_lbd)[k] = lbd;
+        WKA(int2, wl)[cref] = make_int2(l0, l1);
     }
     w.n_learnts++;
     w.lc_lits_n += (uint32_t)n;
     wave_fence();
-    if (!list_push_uniform(w, l0 ^ 1, cref, l1)) return -1;
-    if (!list_push_uniform(w, l1 ^ 1, cref, l0)) return -1;
+    if (!list_push_uniform(w, sh, L, l0 ^ 1, cref, l1)) return -1;
+    if (!list_push_uniform(w, sh, L, l1 ^ 1, cref, l0)) return -1;
     return cref;
 }
 
 // ---- worker load / store -------------------------------------------------------
-DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab) {
-    w.n_vars = sh.n_vars; w.n_orig = sh.n_orig;
-    w.cl_off = sh.cl_off; w.cl_lits = sh.cl_lits; w.bin_off = sh.bin_off; w.bin_lits = sh.bin_lits;
-    w.st = (MsState*)(slab + L.state);
-    w.val = (uint8_t*)(slab + L.val); w.phase = (uint8_t*)(slab + L.phase); w.seen = (uint8_t*)(slab + L.seen);
-    w.level = (int32_t*)(slab + L.level); w.reason = (int32_t*)(slab + L.reason);
-    w.trail = (int32_t*)(slab + L.trail); w.trail_lim = (int32_t*)(slab + L.trail_lim);
-    w.vm_pos = (int32_t*)(slab + L.vm_pos); w.vm_order = (int32_t*)(slab + L.vm_order);
-    w.wl = (int2*)(slab + L.wl);
-    w.w_base = (uint32_t*)(slab + L.w_base); w.w_size = (uint32_t*)(slab + L.w_size); w.w_cap = (uint32_t*)(slab + L.w_cap);
-    w.pool = (int2*)(slab + L.pool);
-    w.lc_off = (uint32_t*)(slab + L.lc_off); w.lc_lbd = (uint32_t*)(slab + L.lc_lbd); w.lc_lits = (int32_t*)(slab + L.lc_lits);
-    w.learnt_buf = (int32_t*)(slab + L.learnt_buf); w.toclear = (int32_t*)(slab + L.toclear);
-    w.lvl_stamp = (uint32_t*)(slab + L.lvl_stamp); w.remap = (uint32_t*)(slab + L.remap);
-    w.overflow = (int32_t*)(slab + L.overflow); w.assumps = (int32_t*)(slab + L.assumps); w.script = (int32_t*)(slab + L.script);
-    w.learnt_cap = L.learnt_cap; w.learnt_lit_cap = L.learnt_lit_cap; w.pool_cap = L.pool_cap; w.vm_cap = L.vm_cap;
-    const MsState* s = w.st;
+template <bool LV>
+DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const MsParams& prm) {
+    w.slab = slab;
+    const MsState* s = WKA(MsState, state);
     w.trail_n = s->trail_n; w.qhead = s->qhead; w.n_levels = s->n_levels;
     w.vm_end = s->vm_end; w.vm_search = s->vm_search;
     w.n_learnts = s->n_learnts; w.lc_lits_n = s->lc_lits_n; w.pool_top = s->pool_top;
     w.status = s->status;
     w.lvl_stamp_ctr = s->lvl_stamp_ctr;
+    w.max_groups = prm.max_groups < 1 ? 1 : (prm.max_groups > MS_MAX_GROUPS ? MS_MAX_GROUPS : prm.max_groups);
     w.ring_lo = w.trail_n;  // nothing staged yet: the queue suffix is re-read from HBM
-    w.confl_kind = 0; w.confl_cref = 0; w.confl_a = 0; w.confl_b = 0;
-    w.c_props = w.c_watch = w.c_move = w.c_enq = w.c_dec = 0; w.c_cl_lit = 0;
+    w.confl_kind = 0; w.confl_cref = 0; w.confl_a = 0; w.confl_b = 0; w.confl_c = 0;
+    w.c_props = w.c_watch = w.c_move = w.c_enq = w.c_dec = w.c_steps = w.c_redo = 0; w.c_cl_lit = 0;
+    if (LV) {  // stage the assignment: bytes in HBM -> 2 bits per variable in LDS
+        const uint8_t* gval = WKA(uint8_t, val);
+        const uint32_t words = (sh.n_vars + 15) >> 4;
+        for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) {
+            uint32_t x = 0;
+            for (uint32_t k = 0; k < 16; k++) {
+                uint32_t v = i * 16 + k;
+                if (v < sh.n_vars) x |= ((uint32_t)gval[v] & 3u) << (2 * k);
+            }
+            w.lval[i] = x;
+        }
+    }
 }
 
-DEV void wk_store(Wk& w, u64 cycles) {
+template <bool LV>
+DEV void wk_store(Wk& w, const MsShared& sh, const MsLayout& L, u64 cycles) {
     u64 cl = wave_sum_u32(w.c_cl_lit);
+    lds_fence();
+    if (LV) {
+        uint8_t* gval = WKA(uint8_t, val);
+        for (uint32_t v = (uint32_t)w.lane; v < sh.n_vars; v += MS_WAVE)
+            gval[v] = (uint8_t)((w.lval[v >> 4] >> ((v & 15) * 2)) & 3u);
+    }
     if (w.lane == 0) {
-        MsState* s = w.st;
+        MsState* s = WKA(MsState, state);
         s->trail_n = w.trail_n; s->qhead = w.qhead; s->n_levels = w.n_levels;
         s->vm_end = w.vm_end; s->vm_search = w.vm_search;
         s->n_learnts = w.n_learnts; s->lc_lits_n = w.lc_lits_n; s->pool_top = w.pool_top;
@@ -778,6 +944,7 @@ DEV void wk_store(Wk& w, u64 cycles) {
         s->propagations += w.c_props; s->decisions += w.c_dec;
         s->n_watch += w.c_watch; s->n_move += w.c_move; s->n_enq += w.c_enq; s->n_cl_lit += cl;
         s->slice_cycles += cycles;
+        s->n_steps += w.c_steps; s->n_redo += w.c_redo;
     }
 }
 
@@ -785,26 +952,31 @@ DEV void wk_store(Wk& w, u64 cycles) {
 // grid = n_workers blocks of 64 threads.  Runs each worker until it has a verdict,
 // or has spent its slice (conflicts / propagations), or the host / another worker
 // raised a stop flag.  All state is persisted in the slab, so the host simply
-// relaunches the kernel to continue.
+// relaunches the kernel to continue.  LV = assignment staged in (dynamic) LDS.
+template <bool LV>
 __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
     __shared__ uint32_t s_hist[64];
     __shared__ uint32_t s_lbdq[64];
     __shared__ uint32_t s_ov;
+    HIP_DYNAMIC_SHARED(uint32_t, s_lval)
     const uint32_t wid = blockIdx.x;
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist;
+    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval;
     if (w.lane == 0) s_ov = 0;
-    wk_bind(w, sh, L, slabs + (size_t)wid * L.slab_bytes);
-    MsState* st = w.st;
+    wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
+    MsState* st = WKA(MsState, state);
     volatile uint32_t* lbdq = s_lbdq;
     if (w.lane < MS_LBDQ) lbdq[w.lane] = st->lbdq[w.lane];
     lds_fence();
     const u64 t0 = __builtin_readcyclecounter();
     const int n_assumps = st->n_assumps;
+    const int32_t* assumps = WK_PTR(int32_t, w, L, assumps);
+    const uint8_t* phase = WK_PTR(uint8_t, w, L, phase);
+    const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
     // restart / reduce state: uniform registers for the slice
     u64 conflicts = st->conflicts, restarts = st->restarts, reduce_dbs = st->reduce_dbs;
     u64 lbdq_sum = st->lbdq_sum, lbd_total = st->lbd_total, next_reduce = st->next_reduce;
@@ -814,7 +986,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
     uint32_t slice_confl = 0;
     const bool entered_running = w.status == MS_ST_RUNNING;
     while (w.status == MS_ST_RUNNING) {
-        if (propagate(w)) {
+        if (propagate<LV>(w, sh, L)) {
             // ---------------- conflict
             slice_confl++;
             conflicts++;
@@ -825,17 +997,17 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
             if (conflicts > 10000 && lbdq_n == MS_LBDQ && (double)w.trail_n > 1.4 * trail_avg) {
                 lbdq_n = 0; lbdq_i = 0; lbdq_sum = 0;
             }
-            Learnt lr = analyze(w);
+            Learnt lr = analyze_call(w, sh, L);
             if (w.status != MS_ST_RUNNING) break;
-            cancel_until(w, lr.bt_level);
+            cancel_until<LV>(w, sh, L, lr.bt_level);
             if (lr.n == 1) {
-                int l0 = uni(w.learnt_buf[0]);  // unit learnt: bt_level is 0
-                if (lit_value(w, l0) == MS_VAL_FALSE) { w.status = MS_ST_UNSAT; break; }
-                enqueue_uniform(w, l0, MS_REASON_NONE);
+                int l0 = uni(learnt_buf[0]);  // unit learnt: bt_level is 0
+                if (lit_value<LV>(w, sh, L, l0) == MS_VAL_FALSE) { w.status = MS_ST_UNSAT; break; }
+                enqueue_uniform<LV>(w, sh, L, l0, MS_REASON_NONE);
             } else {
-                int cref = add_learnt(w, lr.n, lr.lbd);
+                int cref = add_learnt<LV>(w, sh, L, lr.n, lr.lbd);
                 if (cref < 0) break;
-                enqueue_uniform(w, uni(w.learnt_buf[0]), cref);
+                enqueue_uniform<LV>(w, sh, L, uni(learnt_buf[0]), cref);
             }
             learnt_total++;
             learnt_lits_total += (u64)lr.n;
@@ -858,34 +1030,34 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
             if (lbdq_n == MS_LBDQ && ((double)lbdq_sum / MS_LBDQ) * 0.8 > (double)lbd_total / (double)conflicts) {
                 lbdq_n = 0; lbdq_i = 0; lbdq_sum = 0;
                 restarts++;
-                cancel_until(w, 0);
+                cancel_until<LV>(w, sh, L, 0);
             }
-            if (conflicts >= next_reduce || w.n_learnts > w.learnt_cap - w.learnt_cap / 8 ||
-                w.lc_lits_n > w.learnt_lit_cap - w.learnt_lit_cap / 8) {
+            if (conflicts >= next_reduce || w.n_learnts > L.learnt_cap - L.learnt_cap / 8 ||
+                w.lc_lits_n > L.learnt_lit_cap - L.learnt_lit_cap / 8) {
                 reduce_dbs++;
                 next_reduce = conflicts + prm.reduce_first + (u64)prm.reduce_inc * reduce_dbs;
-                reduce_db(w, s_hist);
+                reduce_db_call<LV>(w, sh, L);
             }
-            if (w.pool_top > w.pool_cap - w.pool_cap / 4) rebuild_watches(w);  // pool running low: collect holes
+            if (w.pool_top > L.pool_cap - L.pool_cap / 4) rebuild_watches_call(w, sh, L);  // pool running low: collect holes
             if (w.status != MS_ST_RUNNING) break;
             int next = -1;
             bool refuted = false;
             while (w.n_levels < n_assumps) {
-                int a = uni(w.assumps[w.n_levels]);
-                int va = lit_value(w, a);
-                if (va == MS_VAL_TRUE) new_decision_level(w);      // dummy level
+                int a = uni(assumps[w.n_levels]);
+                int va = lit_value<LV>(w, sh, L, a);
+                if (va == MS_VAL_TRUE) new_decision_level(w, sh, L);      // dummy level
                 else if (va == MS_VAL_FALSE) { refuted = true; break; }
                 else { next = a; break; }
             }
             if (refuted) { w.status = MS_ST_UNSAT; break; }
             if (next < 0) {
-                int v = pick_branch_var(w);
+                int v = pick_branch_var<LV>(w, sh, L);
                 if (v < 0) { w.status = MS_ST_SAT; break; }
                 w.c_dec++;
-                next = uni(2 * v + (int)w.phase[v]);
+                next = uni(2 * v + (int)phase[v]);
             }
-            new_decision_level(w);
-            enqueue_uniform(w, next, MS_REASON_NONE);
+            new_decision_level(w, sh, L);
+            enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);
         }
     }
     if (entered_running && w.status != MS_ST_RUNNING && w.lane == 0 && prm.any_done) atomicExch(prm.any_done, 1);
@@ -897,37 +1069,40 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
         st->lbdq_n = lbdq_n; st->lbdq_i = lbdq_i; st->trail_avg = trail_avg;
         st->learnt_total = learnt_total; st->learnt_lits_total = learnt_lits_total;
     }
-    wk_store(w, __builtin_readcyclecounter() - t0);
+    wk_store<LV>(w, sh, L, __builtin_readcyclecounter() - t0);
 }
 
 // ---- scripted BCP kernel (BASELINE.json configs[1]) -----------------------------------
 // Each worker propagates the formula's own units, then takes its scripted
 // decisions one decision level at a time.  status: MS_ST_SAT is (ab)used as "fixpoint
 // reached without conflict", MS_ST_UNSAT as "conflict".
+template <bool LV>
 __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
     __shared__ uint32_t s_ov;
+    HIP_DYNAMIC_SHARED(uint32_t, s_lval)
     const uint32_t wid = blockIdx.x;
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = nullptr;
+    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = nullptr; w.lval = s_lval;
     if (w.lane == 0) s_ov = 0;
-    wk_bind(w, sh, L, slabs + (size_t)wid * L.slab_bytes);
+    wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     lds_fence();
     const u64 t0 = __builtin_readcyclecounter();
-    const int n_script = w.st->n_script;
-    bool confl = propagate(w);
+    const int n_script = WKA(MsState, state)->n_script;
+    const int32_t* script = WK_PTR(int32_t, w, L, script);
+    bool confl = propagate<LV>(w, sh, L);
     for (int d = 0; d < n_script && !confl && w.status == MS_ST_RUNNING; d++) {
-        int a = uni(w.script[d]);
-        int va = lit_value(w, a);
+        int a = uni(script[d]);
+        int va = lit_value<LV>(w, sh, L, a);
         if (va == MS_VAL_TRUE) continue;
         if (va == MS_VAL_FALSE) { confl = true; break; }
-        new_decision_level(w);
-        enqueue_uniform(w, a, MS_REASON_NONE);
-        confl = propagate(w);
+        new_decision_level(w, sh, L);
+        enqueue_uniform<LV>(w, sh, L, a, MS_REASON_NONE);
+        confl = propagate<LV>(w, sh, L);
     }
     if (w.status == MS_ST_RUNNING) w.status = confl ? MS_ST_UNSAT : MS_ST_SAT;
-    wk_store(w, __builtin_readcyclecounter() - t0);
+    wk_store<LV>(w, sh, L, __builtin_readcyclecounter() - t0);
 }

@@ -3,28 +3,48 @@
 // One *worker* = one 64-lane wavefront running a complete CDCL search (or a
 // scripted BCP) on its own copy of the mutable solver state.  Everything a
 // worker mutates lives in ONE contiguous slab of HBM (`slab_bytes` per
-// worker); everything immutable (clause literals, clause offsets, the binary
-// implication CSR) exists once per GPU and is read by all workers, so it is
-// served from L2 / Infinity Cache while the private slabs stream from HBM.
+// worker); everything immutable exists once per GPU and is read by all workers,
+// so it is served from L2 / Infinity Cache while the private slabs stream from
+// HBM.  Immutable, shared:
+//   * binary clauses   as an implication CSR  (literal p true -> implied literals)
+//   * ternary clauses  as a CSR of literal PAIRS (p true, i.e. ~p false -> the
+//                      other two literals of each clause containing ~p); they need
+//                      no watches, no writes and no private memory at all
+//   * long clauses (>= 4 literals): literals + offsets; each worker keeps only the
+//     two watched literals per clause and its watch lists privately.
 //
 // Literal encoding on the device: lit = 2*var + neg, var 0-based.
 #pragma once
 #include <stdint.h>
 
 #define MS_WAVE 64
-#define MS_LDS_RING 1024          // per-wave propagation queue window in LDS (entries)
-#define MS_CLAIM_SLOTS 256        // per-wave implication claim table in LDS
+#define MS_LDS_RING 256           // per-wave propagation queue window in LDS (entries)
+#define MS_CLAIM_SLOTS 128        // per-wave implication claim table in LDS
 #define MS_OVERFLOW_CAP 192       // watcher pushes that found their list full, per chunk
 #define MS_LBDQ 50                // Glucose restart window
+#define MS_MAX_GROUPS 8           // queue literals propagated per step (lane groups per wave)
+
+// lit_value() results
 #define MS_VAL_TRUE 0
 #define MS_VAL_FALSE 1
 #define MS_VAL_UNDEF 2
+// stored assignment per variable (a byte in HBM, 2 bits in LDS): bit1 = assigned, bit0 = sign
+#define MS_ASG_UNDEF 0
+#define MS_ASG_TRUE 2
+#define MS_ASG_FALSE 3
 
+// reason[] encoding
 #define MS_REASON_NONE (-1)
 // binary reason: the clause (x | other) implied x; stored as -2 - other
 #define MS_REASON_BIN(other) (-2 - (other))
-#define MS_IS_BIN_REASON(r) ((r) <= -2)
+// ternary reason: entry e of the ternary CSR implied one literal of its pair
+#define MS_TERN_BASE (-(1 << 30))
+#define MS_REASON_TERN(e) (MS_TERN_BASE - (int)(e))
+#define MS_IS_TERN_REASON(r) ((r) <= MS_TERN_BASE)
+#define MS_TERN_REASON_ENTRY(r) (MS_TERN_BASE - (r))
+#define MS_IS_BIN_REASON(r) ((r) <= -2 && (r) > MS_TERN_BASE)
 #define MS_BIN_REASON_LIT(r) (-2 - (r))
+#define MS_MAX_VARS (1u << 27)
 
 enum {
     MS_ST_RUNNING = 0,
@@ -36,21 +56,26 @@ enum {
     MS_ST_ERR_INTERNAL = -3,
 };
 
+struct ms_int2 { int32_t x, y; };
+
 // Immutable, one per GPU.
 struct MsShared {
     uint32_t n_vars;
-    uint32_t n_orig;               // long (>=3 literal) original clauses, cref 0..n_orig-1
+    uint32_t n_orig;               // long (>= 4 literal) original clauses, cref 0..n_orig-1
     const uint32_t* cl_off;        // n_orig+1 offsets into cl_lits
     const int32_t* cl_lits;        // literals of the long original clauses
     const uint32_t* bin_off;       // 2*n_vars+1: implications of literal p being TRUE
     const int32_t* bin_lits;       // implied literals q  (clause  ~p | q)
+    const uint32_t* tern_off;      // 2*n_vars+1: ternary clauses containing ~p
+    const ms_int2* tern_pairs;     // the other two literals (b, c) of clause (~p | b | c)
+    const int32_t* tern_owner;     // per entry: the literal p whose list it is in (conflict analysis)
 };
 
 // Byte offsets of the private arrays inside a worker slab.
 struct MsLayout {
     uint64_t slab_bytes;
     uint64_t state;       // MsState
-    uint64_t val;         // uint8  [n_vars]   MS_VAL_*
+    uint64_t val;         // uint8  [n_vars]   MS_ASG_*
     uint64_t phase;       // uint8  [n_vars]   saved sign (1 = assign false)
     uint64_t seen;        // uint8  [n_vars]
     uint64_t level;       // int32  [n_vars]
@@ -63,7 +88,7 @@ struct MsLayout {
     uint64_t w_base;      // uint32 [2*n_vars] start of the literal's watch list in pool
     uint64_t w_size;      // uint32 [2*n_vars]
     uint64_t w_cap;       // uint32 [2*n_vars]
-    uint64_t pool;        // int2   [pool_cap]  watcher = (cref, blocker)
+    uint64_t pool;        // int2   [pool_cap]  watcher = (cref, blocker); cref < 0 = tombstone
     uint64_t lc_off;      // uint32 [learnt_cap+1]
     uint64_t lc_lbd;      // uint32 [learnt_cap]  lbd | used<<31
     uint64_t lc_lits;     // int32  [learnt_lit_cap]
@@ -83,8 +108,7 @@ struct MsState {
     int32_t trail_n, qhead, n_levels;
     int32_t n_assumps;
     int32_t n_script;
-    int32_t conflict_kind;     // scratch
-    int32_t pad0;
+    int32_t pad0[2];
     // decision queue
     int32_t vm_end, vm_search;
     // learnt store
@@ -102,7 +126,9 @@ struct MsState {
     uint64_t n_watch, n_cl_lit, n_move, n_enq;
     uint64_t learnt_total, learnt_lits_total;
     uint64_t slice_cycles;
-    uint64_t reserved[8];
+    uint64_t n_steps;          // BCP steps (each propagates up to MS_MAX_GROUPS literals)
+    uint64_t n_redo;           // literals re-queued because two groups met in one clause
+    uint64_t reserved[6];
 };
 
 // Launch parameters of one slice.
@@ -111,8 +137,8 @@ struct MsParams {
     uint32_t slice_conflicts;      // stop the slice after this many conflicts per worker
     uint64_t slice_props;          // ... or this many propagations (0 = unlimited)
     const volatile int32_t* stop_flag;  // pinned host int: nonzero -> leave the slice early
-    int32_t stop_on_any;           // device-side flag ptr below is set by the first finished worker
-    int32_t mode;                  // 0 = CDCL search, 1 = scripted BCP
+    int32_t stop_on_any;           // leave when any worker has finished (any_done)
+    int32_t max_groups;            // 1..MS_MAX_GROUPS queue literals per BCP step
     int32_t* any_done;             // device int, set when a worker reaches SAT/UNSAT
     uint32_t reduce_first, reduce_inc;
 };

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -141,8 +142,11 @@ struct mi355sat {
     // device
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf<uint32_t> d_cl_off, d_bin_off;
-    DevBuf<int32_t> d_cl_lits, d_bin_lits;
+    DevBuf<uint32_t> d_cl_off, d_bin_off, d_tern_off;
+    DevBuf<int32_t> d_cl_lits, d_bin_lits, d_tern_owner;
+    DevBuf<ms_int2> d_tern_pairs;
+    bool lds_val = false;                      // assignment staged in LDS (2 bits/var)
+    uint32_t lds_val_bytes = 0;
     DevBuf<char> d_template, d_slabs;
     DevBuf<MsState> d_states;
     DevBuf<int32_t> d_any_done, d_assump, d_script;
@@ -170,6 +174,9 @@ struct Prepared {
     std::vector<int32_t> cl_lits;
     std::vector<uint32_t> bin_off;
     std::vector<int32_t> bin_lits;
+    std::vector<uint32_t> tern_off;
+    std::vector<ms_int2> tern_pairs;
+    std::vector<int32_t> tern_owner;
 };
 
 inline int32_t to_internal(int32_t d) { return d > 0 ? 2 * (d - 1) : 2 * (-d - 1) + 1; }
@@ -253,11 +260,13 @@ void prepare(const mi355sat& s, bool simplify, Prepared& P) {
         no.swap(no2);
         nn = no.size() - 1;
     }
-    // split binary / long
+    // split: binary -> implication CSR, ternary -> pair CSR, >= 4 literals -> watched clauses
     std::vector<std::pair<int32_t, int32_t>> bins;
+    std::vector<std::array<int32_t, 3>> terns;
     for (size_t c = 0; c < nn; c++) {
         uint64_t len = no[c + 1] - no[c];
         if (len == 2) bins.push_back({nl[no[c]], nl[no[c] + 1]});
+        else if (len == 3) terns.push_back({nl[no[c]], nl[no[c] + 1], nl[no[c] + 2]});
         else {
             P.cl_lits.insert(P.cl_lits.end(), nl.begin() + no[c], nl.begin() + no[c + 1]);
             P.cl_off.push_back((uint32_t)P.cl_lits.size());
@@ -269,10 +278,29 @@ void prepare(const mi355sat& s, bool simplify, Prepared& P) {
     for (auto& b : bins) { P.bin_off[(b.first ^ 1) + 1]++; P.bin_off[(b.second ^ 1) + 1]++; }
     for (size_t i = 0; i < 2 * (size_t)nv; i++) P.bin_off[i + 1] += P.bin_off[i];
     P.bin_lits.resize(2 * bins.size());
-    std::vector<uint32_t> fill(P.bin_off.begin(), P.bin_off.end() - 1);
-    for (auto& b : bins) {
-        P.bin_lits[fill[b.first ^ 1]++] = b.second;   // ~a -> b
-        P.bin_lits[fill[b.second ^ 1]++] = b.first;   // ~b -> a
+    {
+        std::vector<uint32_t> fill(P.bin_off.begin(), P.bin_off.end() - 1);
+        for (auto& b : bins) {
+            P.bin_lits[fill[b.first ^ 1]++] = b.second;   // ~a -> b
+            P.bin_lits[fill[b.second ^ 1]++] = b.first;   // ~b -> a
+        }
+    }
+    std::sort(terns.begin(), terns.end());
+    terns.erase(std::unique(terns.begin(), terns.end()), terns.end());
+    P.tern_off.assign(2 * (size_t)nv + 1, 0);
+    for (auto& c : terns)
+        for (int k = 0; k < 3; k++) P.tern_off[(c[k] ^ 1) + 1]++;
+    for (size_t i = 0; i < 2 * (size_t)nv; i++) P.tern_off[i + 1] += P.tern_off[i];
+    P.tern_pairs.resize(3 * terns.size());
+    P.tern_owner.resize(3 * terns.size());
+    {
+        std::vector<uint32_t> fill(P.tern_off.begin(), P.tern_off.end() - 1);
+        for (auto& c : terns)
+            for (int k = 0; k < 3; k++) {
+                uint32_t e = fill[c[k] ^ 1]++;          // list of the literal that makes c[k] false
+                P.tern_pairs[e] = ms_int2{c[(k + 1) % 3], c[(k + 2) % 3]};
+                P.tern_owner[e] = c[k] ^ 1;
+            }
     }
 }
 
@@ -352,7 +380,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     st->pool_top = (uint32_t)pool_need;
     s.pool_init = pool_need;
     st->next_reduce = s.opts.reduce_first > 0 ? (uint64_t)s.opts.reduce_first : 2000;
-    memset(T + L.val, MS_VAL_UNDEF, nv);
+    memset(T + L.val, MS_ASG_UNDEF, nv);
     memset(T + L.phase, 1, nv);
     int32_t* reason = (int32_t*)(T + L.reason);
     for (uint32_t v = 0; v < nv; v++) reason[v] = MS_REASON_NONE;
@@ -360,7 +388,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     for (size_t i = 0; i < P.units.size(); i++) {
         int32_t l = P.units[i];
         trail[i] = l;
-        ((uint8_t*)(T + L.val))[l >> 1] = (uint8_t)(l & 1);
+        ((uint8_t*)(T + L.val))[l >> 1] = (uint8_t)(2 | (l & 1));
     }
     int32_t* vm_pos = (int32_t*)(T + L.vm_pos);
     int32_t* vm_order = (int32_t*)(T + L.vm_order);
@@ -390,12 +418,22 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.d_cl_lits.upload(P.cl_lits, s.stream);
     s.d_bin_off.upload(P.bin_off, s.stream);
     s.d_bin_lits.upload(P.bin_lits, s.stream);
+    s.d_tern_off.upload(P.tern_off, s.stream);
+    s.d_tern_pairs.upload(P.tern_pairs.empty() ? std::vector<ms_int2>{ms_int2{0, 0}} : P.tern_pairs, s.stream);
+    s.d_tern_owner.upload(P.tern_owner.empty() ? std::vector<int32_t>{0} : P.tern_owner, s.stream);
     s.sh.n_vars = P.n_vars;
     s.sh.n_orig = (uint32_t)P.cl_off.size() - 1;
     s.sh.cl_off = s.d_cl_off.p;
     s.sh.cl_lits = s.d_cl_lits.p;
     s.sh.bin_off = s.d_bin_off.p;
     s.sh.bin_lits = s.d_bin_lits.p;
+    s.sh.tern_off = s.d_tern_off.p;
+    s.sh.tern_pairs = s.d_tern_pairs.p;
+    s.sh.tern_owner = s.d_tern_owner.p;
+    // assignment in LDS (2 bits per variable) when it leaves room for >= 5 waves per CU
+    s.lds_val_bytes = ((P.n_vars + 15) / 16) * 4;
+    s.lds_val = s.opts.lds_val == 1 || (s.opts.lds_val == 0 && s.lds_val_bytes <= 28 * 1024);
+    if (s.lds_val_bytes > 150 * 1024) s.lds_val = false;
     // worker count limited by free HBM
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -411,8 +449,8 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.d_any_done.alloc(1);
     HIPCHK(hipStreamSynchronize(s.stream));
     if (s.opts.verbose)
-        fprintf(stderr, "[mi355sat] vars=%u long=%u bin=%zu units=%zu slab=%.2f MiB workers=%u\n", P.n_vars,
-                s.sh.n_orig, P.bin_lits.size() / 2, P.units.size(), s.L.slab_bytes / 1048576.0, W);
+        fprintf(stderr, "[mi355sat] vars=%u long=%u tern=%zu bin=%zu units=%zu slab=%.2f MiB workers=%u lds_val=%d\n", P.n_vars,
+                s.sh.n_orig, P.tern_pairs.size() / 3, P.bin_lits.size() / 2, P.units.size(), s.L.slab_bytes / 1048576.0, W, (int)s.lds_val);
 }
 
 // Replicate the template into every worker slab (head + initial watch pool only).
@@ -459,8 +497,9 @@ void gather_states(mi355sat& s, std::vector<MsState>& out) {
 void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
     mi355sat_stats_t& o = s.stats;
     uint64_t learnts = 0, llits = 0;
-    uint64_t props = 0, dec = 0, confl = 0, rest = 0, red = 0, nw = 0, ncl = 0, nm = 0, ne = 0;
+    uint64_t props = 0, dec = 0, confl = 0, rest = 0, red = 0, nw = 0, ncl = 0, nm = 0, ne = 0, steps = 0, redo = 0;
     for (auto& st : sts) {
+        steps += st.n_steps; redo += st.n_redo;
         props += st.propagations; dec += st.decisions; confl += st.conflicts; rest += st.restarts;
         red += st.reduce_dbs; nw += st.n_watch; ncl += st.n_cl_lit; nm += st.n_move; ne += st.n_enq;
         learnts += st.n_learnts; llits += st.lc_lits_n;
@@ -468,6 +507,7 @@ void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
     o.propagations += props; o.decisions += dec; o.conflicts += confl; o.restarts += rest; o.reduce_dbs += red;
     o.n_deq += props; o.n_watch += nw; o.n_cl_lit += ncl; o.n_move += nm; o.n_enq += ne;
     o.learnts = learnts; o.learnt_literals = llits;
+    o.bcp_steps += steps; o.bcp_requeued += redo;
 }
 
 void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_t n_vars_out) {
@@ -477,7 +517,7 @@ void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_
                          hipMemcpyDeviceToHost));
     out.assign(n_vars_out, 0);
     for (uint64_t v = 0; v < n_vars_out && v < s.n_vars; v++)
-        out[v] = val[v] == MS_VAL_TRUE ? 1 : (val[v] == MS_VAL_FALSE ? -1 : -1);  // free vars: false
+        out[v] = val[v] == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
 }
 
 struct SliceResult { float ms; };
@@ -489,15 +529,19 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any) {
     prm.slice_props = 0;
     prm.stop_flag = s.stop_flag;
     prm.stop_on_any = stop_on_any ? 1 : 0;
-    prm.mode = mode;
+    prm.max_groups = s.opts.max_groups > 0 ? s.opts.max_groups : MS_MAX_GROUPS;
     prm.any_done = s.d_any_done.p;
     prm.reduce_first = s.opts.reduce_first > 0 ? (uint32_t)s.opts.reduce_first : 2000u;
     prm.reduce_inc = s.opts.reduce_inc > 0 ? (uint32_t)s.opts.reduce_inc : 300u;
+    const uint32_t dyn = s.lds_val ? s.lds_val_bytes : 0;
     HIPCHK(hipEventRecord(s.ev0, s.stream));
-    if (mode == 0)
-        hipLaunchKernelGGL(ms_search_kernel, dim3(s.n_workers), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
-    else
-        hipLaunchKernelGGL(ms_bcp_kernel, dim3(s.n_workers), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+    if (mode == 0) {
+        if (s.lds_val) hipLaunchKernelGGL(ms_search_kernel<true>, dim3(s.n_workers), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        else hipLaunchKernelGGL(ms_search_kernel<false>, dim3(s.n_workers), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+    } else {
+        if (s.lds_val) hipLaunchKernelGGL(ms_bcp_kernel<true>, dim3(s.n_workers), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        else hipLaunchKernelGGL(ms_bcp_kernel<false>, dim3(s.n_workers), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.ev1, s.stream));
     HIPCHK(hipEventSynchronize(s.ev1));
@@ -693,6 +737,7 @@ void mi355sat_free(mi355sat* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     delete s->sweep;
     s->d_cl_off.release(); s->d_bin_off.release(); s->d_cl_lits.release(); s->d_bin_lits.release();
+    s->d_tern_off.release(); s->d_tern_pairs.release(); s->d_tern_owner.release();
     s->d_template.release(); s->d_slabs.release(); s->d_states.release(); s->d_any_done.release();
     s->d_assump.release(); s->d_script.release(); s->d_assump_off.release(); s->d_script_off.release();
     if (s->stop_flag) (void)hipHostFree(s->stop_flag);
@@ -714,7 +759,7 @@ static int add_clause_impl(mi355sat* s, const int32_t* l, uint64_t n) {
         int32_t d = l[i];
         if (d == 0 || d == INT32_MIN) { s->err = "literal 0 inside a clause"; return MI355SAT_ERR_ARG; }
         uint64_t v = (uint64_t)(d < 0 ? -(int64_t)d : d);
-        if (v > (1u << 28)) { s->err = "variable index too large"; return MI355SAT_ERR_ARG; }
+        if (v > MS_MAX_VARS) { s->err = "variable index too large"; return MI355SAT_ERR_ARG; }
         if (v > s->max_var) s->max_var = v;
     }
     s->lits.insert(s->lits.end(), l, l + n);
@@ -884,8 +929,8 @@ int mi355sat_propagate_batch(mi355sat* s, const int32_t* decisions, const uint64
                                    n_instances, hipMemcpyDeviceToHost));
             for (uint64_t i = 0; i < n_instances; i++)
                 for (uint64_t v = 0; v < n_vars; v++) {
-                    uint8_t x = v < P.n_vars ? raw[i * P.n_vars + v] : MS_VAL_UNDEF;
-                    out_values[i * n_vars + v] = x == MS_VAL_TRUE ? 1 : (x == MS_VAL_FALSE ? -1 : 0);
+                    uint8_t x = v < P.n_vars ? raw[i * P.n_vars + v] : MS_ASG_UNDEF;
+                    out_values[i * n_vars + v] = x == MS_ASG_TRUE ? 1 : (x == MS_ASG_FALSE ? -1 : 0);
                 }
         }
     } catch (HipErr& he) {

@@ -36,7 +36,8 @@ class SolverError(RuntimeError):
 class Mi355SatOpts(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("workers", ctypes.c_int32), ("conflict_budget", ctypes.c_int64),
                 ("slice_conflicts", ctypes.c_int32), ("seed", ctypes.c_uint64), ("verbose", ctypes.c_int32),
-                ("reduce_first", ctypes.c_int32), ("reduce_inc", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+                ("reduce_first", ctypes.c_int32), ("reduce_inc", ctypes.c_int32), ("lds_val", ctypes.c_int32),
+                ("max_groups", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
 class Mi355SatStats(ctypes.Structure):
@@ -46,8 +47,9 @@ class Mi355SatStats(ctypes.Structure):
                [("avg_clause_len", ctypes.c_double), ("solve_seconds", ctypes.c_double),
                 ("kernel_seconds", ctypes.c_double), ("kernel_launches", ctypes.c_uint64)] + \
                [(n, ctypes.c_uint64) for n in
-                ("n_deq", "n_watch", "n_cl_lit", "n_move", "n_enq", "n_sat", "n_unsat", "n_terminated")] + \
-               [("reserved", ctypes.c_uint64 * 8)]
+                ("n_deq", "n_watch", "n_cl_lit", "n_move", "n_enq", "n_sat", "n_unsat", "n_terminated",
+                 "bcp_steps", "bcp_requeued")] + \
+               [("reserved", ctypes.c_uint64 * 6)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
@@ -107,7 +109,7 @@ class Interrupter:
 
 class Mi355Sat:
     def __init__(self, device=-1, workers=0, conflict_budget=0, slice_conflicts=0, seed=0, verbose=0,
-                 reduce_first=0, reduce_inc=0, _lib_override=None):
+                 reduce_first=0, reduce_inc=0, lds_val=0, max_groups=0, _lib_override=None):
         # _lib_override: test hook (the wavefront-emulator build under tests/emu); the product
         # always binds the HIP library and fails loudly without it.
         raw = _lib_override if _lib_override is not None else _lib.solver_lib()
@@ -116,7 +118,7 @@ class Mi355Sat:
         self._L = _bound[id(raw)]
         opts = Mi355SatOpts(device=device, workers=workers, conflict_budget=conflict_budget,
                             slice_conflicts=slice_conflicts, seed=seed, verbose=verbose,
-                            reduce_first=reduce_first, reduce_inc=reduce_inc)
+                            reduce_first=reduce_first, reduce_inc=reduce_inc, lds_val=lds_val, max_groups=max_groups)
         self._h = self._L.mi355sat_new(ctypes.byref(opts))
         if not self._h:
             raise SolverError("mi355sat_new failed: " + (self._L.mi355sat_last_error(None) or b"").decode())
