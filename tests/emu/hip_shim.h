@@ -37,6 +37,7 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
 static inline int2 make_int2(int a, int b) { return int2{a, b}; }
 
 namespace emu {

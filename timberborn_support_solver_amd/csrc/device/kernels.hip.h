@@ -35,6 +35,24 @@
 
 typedef unsigned long long u64;
 
+// Optional per-phase cycle stamps (diagnostic build only: make prof -> libmi355sat_prof.so).
+// Phase totals land in MsState::reserved[0..5] + n_prof[...] and are never read by the solver.
+#ifdef MS_PROFILE
+#define PROF_DECL u64 prof_t_ = __builtin_readcyclecounter();
+#define PROF_MARK(slot)                                              \
+    do {                                                             \
+        u64 n_ = __builtin_readcyclecounter();                       \
+        w.prof[slot] += (n_ - prof_t_);                    \
+        prof_t_ = n_;                                                \
+    } while (0)
+#define PROF_RESET prof_t_ = __builtin_readcyclecounter();
+#else
+#define PROF_DECL
+#define PROF_MARK(slot)
+#define PROF_RESET
+#endif
+enum { PF_OFF = 0, PF_BIN, PF_TERN, PF_LONG, PF_CLOSE, PF_ANALYZE, PF_BACKJUMP, PF_DECIDE, PF_REDUCE, PF_N };
+
 #define DEV __device__ __forceinline__
 // cold paths are real calls: keeps them out of the hot loop's register allocation
 #define DEV_COLD __device__ __noinline__
@@ -60,6 +78,9 @@ struct Wk {
     // per-slice counters (flushed into the 64-bit totals of MsState at slice end)
     uint32_t c_props, c_watch, c_move, c_enq, c_dec, c_steps, c_redo;
     uint32_t c_cl_lit;  // per lane
+#ifdef MS_PROFILE
+    u64 prof[PF_N];
+#endif
 };
 
 // Arrays are addressed through the kernel arguments (scalar registers / scalar loads), not through
@@ -113,15 +134,13 @@ DEV void asg_clear(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
 
 DEV void clause_range(const Wk& w, const MsShared& sh, const MsLayout& L, int c, const int32_t*& lits, int& size) {
     if ((uint32_t)c < sh.n_orig) {
-        uint32_t o0 = sh.cl_off[c], o1 = sh.cl_off[c + 1];
-        lits = sh.cl_lits + o0;
-        size = (int)(o1 - o0);
+        const MsClauseHdr h = sh.cl_hdr[c];
+        lits = sh.cl_lits + h.start;
+        size = (int)h.size;
     } else {
-        uint32_t k = (uint32_t)c - sh.n_orig;
-        const uint32_t* lc_off = WK_PTR(uint32_t, w, L, lc_off);
-        uint32_t o0 = lc_off[k], o1 = lc_off[k + 1];
-        lits = WK_PTR(int32_t, w, L, lc_lits) + o0;
-        size = (int)(o1 - o0);
+        const MsClauseHdr h = WKA(MsClauseHdr, lc_hdr)[(uint32_t)c - sh.n_orig];
+        lits = WKA(int32_t, lc_lits) + h.start;
+        size = (int)h.size;
     }
 }
 
@@ -206,20 +225,23 @@ DEV void commit_implications(Wk& w, const MsShared& sh, const MsLayout& L, bool 
 // Append (cref, blocker) to the list of literal t (uniform call, rare path:
 // learnt clause attach and overflow repair).  Grows the list from the bump pool.
 DEV bool list_push_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int t, int cref, int blocker) {
-    uint32_t s = (uint32_t)uni((int)WKA(uint32_t, w_size)[t]);
-    uint32_t cap = (uint32_t)uni((int)WKA(uint32_t, w_cap)[t]);
+    MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
+    int2* pool = WKA(int2, pool);
+    uint32_t s = (uint32_t)uni((int)whdr[t].size);
+    uint32_t cap = (uint32_t)uni((int)whdr[t].cap);
     if (s > cap) s = cap;  // overshoot left by failed atomic pushes
-    uint32_t base = (uint32_t)uni((int)WKA(uint32_t, w_base)[t]);
+    uint32_t base = (uint32_t)uni((int)whdr[t].base);
     if (s == cap) {
         uint32_t ncap = cap < 4 ? 8 : cap * 2;
         if (w.pool_top + ncap > L.pool_cap) { w.status = MS_ST_ERR_POOL; return false; }
         uint32_t nb = w.pool_top;
         w.pool_top += ncap;
-        for (uint32_t i = (uint32_t)w.lane; i < s; i += MS_WAVE) WKA(int2, pool)[nb + i] = WKA(int2, pool)[base + i];
-        if (w.lane == 0) { WKA(uint32_t, w_base)[t] = nb; WKA(uint32_t, w_cap)[t] = ncap; }
+        for (uint32_t i = (uint32_t)w.lane; i < s; i += MS_WAVE) pool[nb + i] = pool[base + i];
+        wave_fence();
+        if (w.lane == 0) { whdr[t].base = nb; whdr[t].cap = ncap; }
         base = nb;
     }
-    if (w.lane == 0) { WKA(int2, pool)[base + s] = make_int2(cref, blocker); WKA(uint32_t, w_size)[t] = s + 1; }
+    if (w.lane == 0) { pool[base + s] = make_int2(cref, blocker); whdr[t].size = s + 1; }
     wave_fence();
     return true;
 }
@@ -237,11 +259,41 @@ DEV void repair_overflow(Wk& w, const MsShared& sh, const MsLayout& L) {
     lds_fence();
 }
 
+// Find a non-false literal of clause `cl[0..size)` other than fl / other: 4 literals per load
+// (clause literals are 16-byte aligned), the first `MS_LANE_SCAN` by the visiting lane itself.
+#define MS_LANE_SCAN 8
+template <bool LV>
+DEV int scan_head(const Wk& w, const MsShared& sh, const MsLayout& L, const int32_t* cl, int size, int fl, int other,
+                  uint32_t& nl) {
+    const int lim = size < MS_LANE_SCAN ? size : MS_LANE_SCAN;
+    for (int k = 0; k < lim; k += 4) {
+        const int4 q = *(const int4*)(cl + k);
+        const int ls[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int l = ls[u];
+            if (k + u >= size || l == fl || l == other) continue;
+            nl++;
+            if (lit_value<LV>(w, sh, L, l) != MS_VAL_FALSE) return l;
+        }
+    }
+    return -1;
+}
+
 // Unit propagation to fixpoint.  Returns true on conflict (w.confl_*).
 template <bool LV>
 DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
     w.confl_kind = 0;
+    MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
+    int2* pool = WKA(int2, pool);
+    int2* wl = WKA(int2, wl);
+    const int32_t* trail = WKA(int32_t, trail);
+    // headers prefetched for the NEXT step (queue literal index pf_idx), loaded while this step runs
+    int pf_idx = -1, pf_p = 0;
+    MsLitHdr pf_lh = {0, 0, 0, 0};
+    MsWatchHdr pf_wh = {0, 0, 0, 0};
     while (w.qhead < w.trail_n && w.status == MS_ST_RUNNING) {
+        PROF_DECL
         // ---- split the wave into G groups of S lanes, one queue literal per group
         const int qlen = w.trail_n - w.qhead;
         int lg = qlen >= 8 ? 3 : (qlen >= 4 ? 2 : (qlen >= 2 ? 1 : 0));
@@ -251,12 +303,33 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const u64 gmask = (S == MS_WAVE ? ~0ull : ((1ull << S) - 1ull)) << (g * S);
         const int qbase = w.qhead;
         const int idx = qbase + g;
-        const int p = (idx >= w.ring_lo) ? w.ring[idx & (MS_LDS_RING - 1)] : WKA(int32_t, trail)[idx];
+        int p;
+        MsLitHdr lh;
+        MsWatchHdr wh;
+        if (idx == pf_idx) { p = pf_p; lh = pf_lh; wh = pf_wh; }
+        else {
+            p = (idx >= w.ring_lo) ? w.ring[idx & (MS_LDS_RING - 1)] : trail[idx];
+            lh = sh.lit_hdr[p];
+            wh = whdr[p];
+        }
         const int fl = p ^ 1;
-        const uint32_t b0 = sh.bin_off[p], b1 = sh.bin_off[p + 1];
-        const uint32_t t0 = sh.tern_off[p], t1 = sh.tern_off[p + 1];
-        const uint32_t wb = WKA(uint32_t, w_base)[p];
-        const int n = (int)WKA(uint32_t, w_size)[p];
+        const uint32_t b0 = lh.bin_off, nb = lh.bin_n, t0 = lh.tern_off, nt = lh.tern_n;
+        const uint32_t wb = wh.base;
+        const int n = (int)wh.size;
+        // first chunk of all three lists in one round trip
+        int q0 = (uint32_t)sl < nb ? sh.bin_lits[b0 + sl] : 0;
+        int2 pr0 = (uint32_t)sl < nt ? ((const int2*)sh.tern_pairs)[t0 + sl] : make_int2(0, 0);
+        int2 wt0 = sl < n ? pool[wb + sl] : make_int2(-1, 0);
+        {   // prefetch the headers the next step will most likely use (same split, next G queue literals)
+            const int nidx = qbase + G + g;
+            pf_idx = -1;
+            if (nidx < w.trail_n) {
+                pf_idx = nidx;
+                pf_p = (nidx >= w.ring_lo) ? w.ring[nidx & (MS_LDS_RING - 1)] : trail[nidx];
+                pf_lh = sh.lit_hdr[pf_p];
+                pf_wh = whdr[pf_p];
+            }
+        }
         w.qhead += G;
         w.c_props += (uint32_t)G;
         w.c_steps++;
@@ -265,11 +338,12 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         int bf[MS_MAX_GROUPS];
 #pragma unroll
         for (int gg = 0; gg < MS_MAX_GROUPS; gg++) bf[gg] = gg < G ? __shfl(fl, gg * S, 64) : -1;
+        PROF_MARK(PF_OFF);
         // ---- binary implications ------------------------------------------
-        for (uint32_t it = 0; ballot(b0 + it * S < b1) != 0; it++) {
-            const uint32_t i = b0 + it * S + (uint32_t)sl;
-            const bool act = i < b1;
-            const int q = act ? sh.bin_lits[i] : 0;
+        for (uint32_t it = 0; ballot(it * S < nb) != 0; it++) {
+            const uint32_t i = it * S + (uint32_t)sl;
+            const bool act = i < nb;
+            const int q = it == 0 ? q0 : (act ? sh.bin_lits[b0 + i] : 0);
             const int vq = act ? lit_value<LV>(w, sh, L, q) : MS_VAL_TRUE;
             w.c_watch += (uint32_t)popc64(ballot(act));
             commit_implications<LV>(w, sh, L, vq == MS_VAL_UNDEF, q, MS_REASON_BIN(fl), lost);
@@ -283,19 +357,20 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 return true;
             }
         }
+        PROF_MARK(PF_BIN);
         // ---- ternary clauses: literal pairs, shared and read-only ---------
-        for (uint32_t it = 0; ballot(t0 + it * S < t1) != 0; it++) {
-            const uint32_t i = t0 + it * S + (uint32_t)sl;
-            const bool act = i < t1;
-            const int2 pr = act ? ((const int2*)sh.tern_pairs)[i] : make_int2(0, 0);
+        for (uint32_t it = 0; ballot(it * S < nt) != 0; it++) {
+            const uint32_t i = it * S + (uint32_t)sl;
+            const bool act = i < nt;
+            const int2 pr = it == 0 ? pr0 : (act ? ((const int2*)sh.tern_pairs)[t0 + i] : make_int2(0, 0));
             const int vb = act ? lit_value<LV>(w, sh, L, pr.x) : MS_VAL_TRUE;
             const int vc = act ? lit_value<LV>(w, sh, L, pr.y) : MS_VAL_TRUE;
             w.c_watch += (uint32_t)popc64(ballot(act));
             const bool sat = vb == MS_VAL_TRUE || vc == MS_VAL_TRUE;
-            bool cf = !sat && vb == MS_VAL_FALSE && vc == MS_VAL_FALSE;
+            const bool cf = !sat && vb == MS_VAL_FALSE && vc == MS_VAL_FALSE;
             const bool want = !sat && !cf && (vb == MS_VAL_FALSE || vc == MS_VAL_FALSE);
             const int imp = vb == MS_VAL_FALSE ? pr.y : pr.x;
-            commit_implications<LV>(w, sh, L, want, imp, MS_REASON_TERN(i), lost);
+            commit_implications<LV>(w, sh, L, want, imp, MS_REASON_TERN(t0 + i), lost);
             const u64 cm = ballot(cf || lost);
             if (cm) {
                 const int f = first_lane(cm);
@@ -307,6 +382,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 return true;
             }
         }
+        PROF_MARK(PF_TERN);
         // ---- long + learnt clauses: two watched literals ------------------
         int j = 0;          // kept watchers of my group's list so far
         int done = 0;       // list entries of my group's list already visited
@@ -314,16 +390,19 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         for (int it = 0; ballot(it * S < n) != 0; it++) {
             const int i = it * S + sl;
             const bool act = i < n;
-            int2 wt = act ? WKA(int2, pool)[wb + i] : make_int2(-1, 0);
+            int2 wt = it == 0 ? wt0 : (act ? pool[wb + i] : make_int2(-1, 0));
             const bool live = act && wt.x >= 0;       // cref < 0: tombstone left by an interrupted pass
             bool keep = live, want = false, cf = false, deferred = false;
-            int imp = 0;
+            // phase A (per lane): blocker, the other watch, the first literals of the clause
+            bool scanning = false, need_tail = false;
+            int other = 0, vo = MS_VAL_TRUE, r = -1, size = 0;
+            const int32_t* cl = nullptr;
+            uint32_t nl = 0;
             if (live && lit_value<LV>(w, sh, L, wt.y) != MS_VAL_TRUE) {
-                const int c = wt.x;
-                const int2 ww = WKA(int2, wl)[c];
-                const int other = (ww.x == fl) ? ww.y : ww.x;
-                const int vo = lit_value<LV>(w, sh, L, other);
-                uint32_t nl = 2;
+                const int2 ww = wl[wt.x];
+                other = (ww.x == fl) ? ww.y : ww.x;
+                vo = lit_value<LV>(w, sh, L, other);
+                nl = 2;
                 if (vo == MS_VAL_TRUE) wt.y = other;
                 else {
                     // both watches false and the other one is being propagated by another group in
@@ -336,41 +415,57 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                     if (other_lower) deferred = true;
                     else {
                         wt.y = other;
-                        const int32_t* cl;
-                        int size;
-                        clause_range(w, sh, L, c, cl, size);
-                        int r = -1;
-                        for (int k = 0; k < size; k++) {
-                            int l = cl[k];
-                            if (l == fl || l == other) continue;
-                            nl++;
-                            if (lit_value<LV>(w, sh, L, l) != MS_VAL_FALSE) { r = l; break; }
-                        }
-                        if (r >= 0) {
-                            WKA(int2, wl)[c] = make_int2(other, r);
-                            const int t = r ^ 1;
-                            uint32_t pos = atomicAdd(&WKA(uint32_t, w_size)[t], 1u);
-                            if (pos < WKA(uint32_t, w_cap)[t]) WKA(int2, pool)[WKA(uint32_t, w_base)[t] + pos] = wt;
-                            else {
-                                uint32_t o = atomicAdd((uint32_t*)w.ov_cnt, 1u);
-                                int32_t* ov = WK_PTR(int32_t, w, L, overflow);
-                                ov[3 * o] = t;
-                                ov[3 * o + 1] = c;
-                                ov[3 * o + 2] = other;
-                            }
-                            keep = false;
-                        } else if (vo == MS_VAL_FALSE) cf = true;
-                        else { want = true; imp = other; }
+                        scanning = true;
+                        clause_range(w, sh, L, wt.x, cl, size);
+                        r = scan_head<LV>(w, sh, L, cl, size, fl, other, nl);
+                        need_tail = r < 0 && size > MS_LANE_SCAN;
                     }
                 }
-                w.c_cl_lit += nl;
             }
+            // phase B (whole wave, one clause at a time): the tail of long clauses, 64 literals per load
+            for (u64 tm = ballot(need_tail); tm != 0; tm &= tm - 1) {
+                const int f = first_lane(tm);
+                const unsigned long long cp = (unsigned long long)cl;
+                const int32_t* clf = (const int32_t*)(((unsigned long long)(uint32_t)bcast((int)(cp >> 32), f) << 32) |
+                                                      (unsigned long long)(uint32_t)bcast((int)cp, f));
+                const int szf = bcast(size, f), flf = bcast(fl, f), of = bcast(other, f);
+                int found = -1;
+                for (int k0 = MS_LANE_SCAN; k0 < szf && found < 0; k0 += MS_WAVE) {
+                    const int k = k0 + w.lane;
+                    const int l = k < szf ? clf[k] : flf;
+                    const bool ok = k < szf && l != flf && l != of && lit_value<LV>(w, sh, L, l) != MS_VAL_FALSE;
+                    const u64 om = ballot(ok);
+                    if (om) found = bcast(l, first_lane(om));
+                }
+                if (w.lane == f) { r = found; nl += (uint32_t)(szf - MS_LANE_SCAN); }
+            }
+            // phase C (per lane): move the watch, or report unit / conflict
+            int imp = 0;
+            if (scanning) {
+                if (r >= 0) {
+                    wl[wt.x] = make_int2(other, r);
+                    const int t = r ^ 1;
+                    const uint32_t pos = atomicAdd(&whdr[t].size, 1u);
+                    const MsWatchHdr th = whdr[t];
+                    if (pos < th.cap) pool[th.base + pos] = wt;
+                    else {
+                        uint32_t o = atomicAdd((uint32_t*)w.ov_cnt, 1u);
+                        int32_t* ov = WK_PTR(int32_t, w, L, overflow);
+                        ov[3 * o] = t;
+                        ov[3 * o + 1] = wt.x;
+                        ov[3 * o + 2] = other;
+                    }
+                    keep = false;
+                } else if (vo == MS_VAL_FALSE) cf = true;
+                else { want = true; imp = other; }
+            }
+            w.c_cl_lit += nl;
             w.c_watch += (uint32_t)popc64(ballot(live));
             w.c_move += (uint32_t)popc64(ballot(live && !keep));
             // in-place compaction of the kept watchers of each group's list (dest <= source)
             const u64 km = ballot(keep);
             wave_fence();
-            if (keep) WKA(int2, pool)[wb + j + popc64(km & gmask & lanemask_lt(w.lane))] = wt;
+            if (keep) pool[wb + j + popc64(km & gmask & lanemask_lt(w.lane))] = wt;
             j += popc64(km & gmask);
             done = min(n, (it + 1) * S);
             const u64 dm = ballot(deferred);
@@ -385,20 +480,23 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
             }
             if (w.status != MS_ST_RUNNING) break;
         }
+        PROF_MARK(PF_LONG);
         // close each group's list: fully visited -> new size; interrupted -> tombstone the gap
         // between the compacted prefix and the first unvisited entry
         wave_fence();
         if (done == n) {
-            if (sl == 0 && n > 0) WKA(uint32_t, w_size)[p] = (uint32_t)j;
+            if (sl == 0 && n > 0) whdr[p].size = (uint32_t)j;
         } else {
-            for (int x = j + sl; x < done; x += S) WKA(int2, pool)[wb + x] = make_int2(-1, 0);
+            for (int x = j + sl; x < done; x += S) pool[wb + x] = make_int2(-1, 0);
         }
         wave_fence();
+        PROF_MARK(PF_CLOSE);
         if (w.confl_kind) { w.qhead = w.trail_n; return true; }
         if (defer_g < G) {  // re-queue the deferred group's literal and everything after it
             w.qhead = qbase + defer_g;
             w.c_props -= (uint32_t)(G - defer_g);
             w.c_redo += (uint32_t)(G - defer_g);
+            pf_idx = -1;
         }
     }
     return false;
@@ -700,20 +798,23 @@ DEV Learnt analyze_call(Wk& w, const MsShared& sh, const MsLayout& L) {
 // per-clause watched-literal pairs (no read of the old pool): count, exclusive scan
 // over the 2*n_vars lists (wave prefix sums), fill.  Runs at a propagation fixpoint.
 DEV_COLD void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
+    MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
+    int2* pool = WKA(int2, pool);
+    const int2* wl = WKA(int2, wl);
     const uint32_t nlist = 2 * sh.n_vars;
     const uint32_t ncl = sh.n_orig + w.n_learnts;
-    for (uint32_t t = (uint32_t)w.lane; t < nlist; t += MS_WAVE) WKA(uint32_t, w_size)[t] = 0;
+    for (uint32_t t = (uint32_t)w.lane; t < nlist; t += MS_WAVE) whdr[t].size = 0;
     wave_fence();
     for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
-        int2 ww = WKA(int2, wl)[c];
-        atomicAdd(&WKA(uint32_t, w_size)[ww.x ^ 1], 1u);
-        atomicAdd(&WKA(uint32_t, w_size)[ww.y ^ 1], 1u);
+        int2 ww = wl[c];
+        atomicAdd(&whdr[ww.x ^ 1].size, 1u);
+        atomicAdd(&whdr[ww.y ^ 1].size, 1u);
     }
     wave_fence();
     uint32_t run = 0;
     for (uint32_t t0 = 0; t0 < nlist; t0 += MS_WAVE) {
         uint32_t t = t0 + (uint32_t)w.lane;
-        uint32_t sz = t < nlist ? WKA(uint32_t, w_size)[t] : 0;
+        uint32_t sz = t < nlist ? whdr[t].size : 0;
         uint32_t cap = t < nlist ? sz + (sz >> 1) + 2 : 0;
         uint32_t incl = cap;
         for (int o = 1; o < MS_WAVE; o <<= 1) {
@@ -721,18 +822,18 @@ DEV_COLD void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
             if (w.lane >= o) incl += x;
         }
         wave_fence();
-        if (t < nlist) { WKA(uint32_t, w_base)[t] = run + incl - cap; WKA(uint32_t, w_cap)[t] = cap; WKA(uint32_t, w_size)[t] = 0; }
+        if (t < nlist) whdr[t] = MsWatchHdr{run + incl - cap, 0, cap, 0};
         run += (uint32_t)bcast((int)incl, 63);
     }
     if (run > L.pool_cap) { w.status = MS_ST_ERR_POOL; return; }
     w.pool_top = run;
     wave_fence();
     for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
-        int2 ww = WKA(int2, wl)[c];
-        uint32_t pa = atomicAdd(&WKA(uint32_t, w_size)[ww.x ^ 1], 1u);
-        WKA(int2, pool)[WKA(uint32_t, w_base)[ww.x ^ 1] + pa] = make_int2((int)c, ww.y);
-        uint32_t pb = atomicAdd(&WKA(uint32_t, w_size)[ww.y ^ 1], 1u);
-        WKA(int2, pool)[WKA(uint32_t, w_base)[ww.y ^ 1] + pb] = make_int2((int)c, ww.x);
+        int2 ww = wl[c];
+        uint32_t pa = atomicAdd(&whdr[ww.x ^ 1].size, 1u);
+        pool[whdr[ww.x ^ 1].base + pa] = make_int2((int)c, ww.y);
+        uint32_t pb = atomicAdd(&whdr[ww.y ^ 1].size, 1u);
+        pool[whdr[ww.y ^ 1].base + pb] = make_int2((int)c, ww.x);
     }
     wave_fence();
 }
@@ -744,7 +845,7 @@ DEV_COLD void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
 template <bool LV>
 DEV_COLD void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
     volatile uint32_t* hist = w.hist;
-    uint32_t* lc_off = WK_PTR(uint32_t, w, L, lc_off);
+    MsClauseHdr* lc_hdr = WK_PTR(MsClauseHdr, w, L, lc_hdr);
     uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
     int32_t* lc_lits = WK_PTR(int32_t, w, L, lc_lits);
     uint32_t* remap = WK_PTR(uint32_t, w, L, remap);
@@ -779,8 +880,9 @@ DEV_COLD void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
             uint32_t raw = lc_lbd[k];
             lb = raw & 0x7fffffffu;
             bool used = raw >> 31;
-            o0 = lc_off[k];
-            o1 = lc_off[k + 1];
+            const MsClauseHdr ch = lc_hdr[k];
+            o0 = ch.start;
+            o1 = ch.start + ch.size;
             ww = WKA(int2, wl)[sh.n_orig + k];
             int cref = (int)(sh.n_orig + k);
             bool locked = (lit_value<LV>(w, sh, L, ww.x) == MS_VAL_TRUE && WKA(int32_t, reason)[ww.x >> 1] == cref) ||
@@ -800,14 +902,14 @@ DEV_COLD void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
         bool keep = act && !del;
         u64 km = ballot(keep);
         uint32_t nkeep = (uint32_t)popc64(km);
-        // exclusive prefix of literal counts among kept clauses
-        uint32_t len = keep ? (o1 - o0) : 0, pre = len;
+        // exclusive prefix of (16-byte aligned) literal counts among kept clauses
+        uint32_t len = keep ? (o1 - o0) : 0, pre = (len + 3u) & ~3u;
         for (int o = 1; o < MS_WAVE; o <<= 1) {
             uint32_t t = (uint32_t)__shfl_up((int)pre, o, 64);
             if (w.lane >= o) pre += t;
         }
         uint32_t total = (uint32_t)bcast((int)pre, 63);
-        pre -= len;
+        pre -= (len + 3u) & ~3u;
         uint32_t nkk = nk + (uint32_t)popc64(km & lanemask_lt(w.lane));
         if (act) remap[k] = keep ? nkk : 0xffffffffu;
         wave_fence();
@@ -826,7 +928,7 @@ DEV_COLD void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
                 }
         }
         if (keep) {
-            lc_off[nkk] = nlits + pre;
+            lc_hdr[nkk] = MsClauseHdr{nlits + pre, len};
             lc_lbd[nkk] = lb;  // clears the used bit
             WKA(int2, wl)[sh.n_orig + nkk] = ww;
         }
@@ -834,7 +936,6 @@ DEV_COLD void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
         nlits += total;
         wave_fence();
     }
-    if (w.lane == 0) lc_off[nk] = nlits;
     // pass 2: lay the watch lists out again without the deleted clauses (also collects pool garbage)
     w.n_learnts = nk;
     w.lc_lits_n = nlits;
@@ -868,29 +969,27 @@ DEV void rebuild_watches_call(Wk& w, const MsShared& sh, const MsLayout& L) {
 // Store the clause in learnt_buf[0..n) and attach it.  Returns its cref (or -1).
 template <bool LV>
 DEV int add_learnt(Wk& w, const MsShared& sh, const MsLayout& L, int n, uint32_t lbd) {
-    if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n > L.learnt_lit_cap) {
+    if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n + 8 > L.learnt_lit_cap) {
         reduce_db_call<LV>(w, sh, L);  // store full before the scheduled reduction: reduce now (state is consistent here)
         if (w.status != MS_ST_RUNNING) return -1;
-        if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n > L.learnt_lit_cap) {
+        if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n + 8 > L.learnt_lit_cap) {
             w.status = MS_ST_ERR_LEARNT;
             return -1;
         }
     }
     const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
-    uint32_t* lc_off = WK_PTR(uint32_t, w, L, lc_off);
     int32_t* lc_lits = WK_PTR(int32_t, w, L, lc_lits);
     const uint32_t k = w.n_learnts, o = w.lc_lits_n;
     for (int i = w.lane; i < n; i += MS_WAVE) lc_lits[o + i] = learnt_buf[i];
     const int l0 = uni(learnt_buf[0]), l1 = uni(learnt_buf[1]);
     const int cref = (int)(sh.n_orig + k);
     if (w.lane == 0) {
-        lc_off[k] = o;
-        lc_off[k + 1] = o + (uint32_t)n;
+        WK_PTR(MsClauseHdr, w, L, lc_hdr)[k] = MsClauseHdr{o, (uint32_t)n};
         WK_PTR(uint32_t, w, L, lc_lbd)[k] = lbd;
         WKA(int2, wl)[cref] = make_int2(l0, l1);
     }
     w.n_learnts++;
-    w.lc_lits_n += (uint32_t)n;
+    w.lc_lits_n += ((uint32_t)n + 3u) & ~3u;   // next clause starts 16-byte aligned
     wave_fence();
     if (!list_push_uniform(w, sh, L, l0 ^ 1, cref, l1)) return -1;
     if (!list_push_uniform(w, sh, L, l1 ^ 1, cref, l0)) return -1;
@@ -911,6 +1010,9 @@ DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const
     w.ring_lo = w.trail_n;  // nothing staged yet: the queue suffix is re-read from HBM
     w.confl_kind = 0; w.confl_cref = 0; w.confl_a = 0; w.confl_b = 0; w.confl_c = 0;
     w.c_props = w.c_watch = w.c_move = w.c_enq = w.c_dec = w.c_steps = w.c_redo = 0; w.c_cl_lit = 0;
+#ifdef MS_PROFILE
+    for (int i = 0; i < PF_N; i++) w.prof[i] = 0;
+#endif
     if (LV) {  // stage the assignment: bytes in HBM -> 2 bits per variable in LDS
         const uint8_t* gval = WKA(uint8_t, val);
         const uint32_t words = (sh.n_vars + 15) >> 4;
@@ -945,6 +1047,9 @@ DEV void wk_store(Wk& w, const MsShared& sh, const MsLayout& L, u64 cycles) {
         s->n_watch += w.c_watch; s->n_move += w.c_move; s->n_enq += w.c_enq; s->n_cl_lit += cl;
         s->slice_cycles += cycles;
         s->n_steps += w.c_steps; s->n_redo += w.c_redo;
+#ifdef MS_PROFILE
+        for (int i = 0; i < PF_N; i++) s->prof[i] += w.prof[i];
+#endif
     }
 }
 
@@ -997,7 +1102,9 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
             if (conflicts > 10000 && lbdq_n == MS_LBDQ && (double)w.trail_n > 1.4 * trail_avg) {
                 lbdq_n = 0; lbdq_i = 0; lbdq_sum = 0;
             }
+            PROF_DECL
             Learnt lr = analyze_call(w, sh, L);
+            PROF_MARK(PF_ANALYZE);
             if (w.status != MS_ST_RUNNING) break;
             cancel_until<LV>(w, sh, L, lr.bt_level);
             if (lr.n == 1) {
@@ -1009,6 +1116,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
                 if (cref < 0) break;
                 enqueue_uniform<LV>(w, sh, L, uni(learnt_buf[0]), cref);
             }
+            PROF_MARK(PF_BACKJUMP);
             learnt_total++;
             learnt_lits_total += (u64)lr.n;
             lbdq_sum += lr.lbd;
@@ -1027,6 +1135,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
             if (w.status != MS_ST_RUNNING) break;
             if (prm.slice_props && w.c_props >= prm.slice_props) break;
             // ---------------- no conflict: restart? reduce? decide
+            PROF_DECL
             if (lbdq_n == MS_LBDQ && ((double)lbdq_sum / MS_LBDQ) * 0.8 > (double)lbd_total / (double)conflicts) {
                 lbdq_n = 0; lbdq_i = 0; lbdq_sum = 0;
                 restarts++;
@@ -1038,7 +1147,8 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
                 next_reduce = conflicts + prm.reduce_first + (u64)prm.reduce_inc * reduce_dbs;
                 reduce_db_call<LV>(w, sh, L);
             }
-            if (w.pool_top > L.pool_cap - L.pool_cap / 4) rebuild_watches_call(w, sh, L);  // pool running low: collect holes
+            if (w.pool_top > L.pool_cap - L.pool_cap / 4) rebuild_watches_call(w, sh, L);
+            PROF_MARK(PF_REDUCE);  // pool running low: collect holes
             if (w.status != MS_ST_RUNNING) break;
             int next = -1;
             bool refuted = false;
@@ -1058,6 +1168,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
             }
             new_decision_level(w, sh, L);
             enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);
+            PROF_MARK(PF_DECIDE);
         }
     }
     if (entered_running && w.status != MS_ST_RUNNING && w.lane == 0 && prm.any_done) atomicExch(prm.any_done, 1);

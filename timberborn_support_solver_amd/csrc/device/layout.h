@@ -57,16 +57,21 @@ enum {
 };
 
 struct ms_int2 { int32_t x, y; };
+// Per-literal list header of the shared CSRs: ONE 16-byte load per dequeued literal.
+struct MsLitHdr { uint32_t bin_off, bin_n, tern_off, tern_n; };
+// Per-literal header of the private watch list: ONE 16-byte load; `size` is the atomic push counter.
+struct MsWatchHdr { uint32_t base, size, cap, pad; };
+// Long / learnt clause header: literals start 16-byte aligned (4 literals) so that a lane reads 4 at a time.
+struct MsClauseHdr { uint32_t start, size; };
 
 // Immutable, one per GPU.
 struct MsShared {
     uint32_t n_vars;
     uint32_t n_orig;               // long (>= 4 literal) original clauses, cref 0..n_orig-1
-    const uint32_t* cl_off;        // n_orig+1 offsets into cl_lits
-    const int32_t* cl_lits;        // literals of the long original clauses
-    const uint32_t* bin_off;       // 2*n_vars+1: implications of literal p being TRUE
-    const int32_t* bin_lits;       // implied literals q  (clause  ~p | q)
-    const uint32_t* tern_off;      // 2*n_vars+1: ternary clauses containing ~p
+    const MsClauseHdr* cl_hdr;     // n_orig headers into cl_lits
+    const int32_t* cl_lits;        // literals of the long original clauses (each clause 16-byte aligned)
+    const MsLitHdr* lit_hdr;       // 2*n_vars: where literal p's binary / ternary lists are
+    const int32_t* bin_lits;       // implied literals q  (clause  ~p | q) of p being TRUE
     const ms_int2* tern_pairs;     // the other two literals (b, c) of clause (~p | b | c)
     const int32_t* tern_owner;     // per entry: the literal p whose list it is in (conflict analysis)
 };
@@ -85,13 +90,11 @@ struct MsLayout {
     uint64_t vm_pos;      // int32  [n_vars]   index of the var's live entry in vm_order
     uint64_t vm_order;    // int32  [vm_cap]   move-to-front queue as an append-only array
     uint64_t wl;          // int2   [n_orig + learnt_cap]  the two watched literals per clause
-    uint64_t w_base;      // uint32 [2*n_vars] start of the literal's watch list in pool
-    uint64_t w_size;      // uint32 [2*n_vars]
-    uint64_t w_cap;       // uint32 [2*n_vars]
+    uint64_t whdr;        // MsWatchHdr [2*n_vars]  the literal's watch list: slot in pool, size, capacity
     uint64_t pool;        // int2   [pool_cap]  watcher = (cref, blocker); cref < 0 = tombstone
-    uint64_t lc_off;      // uint32 [learnt_cap+1]
+    uint64_t lc_hdr;      // MsClauseHdr [learnt_cap]
     uint64_t lc_lbd;      // uint32 [learnt_cap]  lbd | used<<31
-    uint64_t lc_lits;     // int32  [learnt_lit_cap]
+    uint64_t lc_lits;     // int32  [learnt_lit_cap]  (each clause 16-byte aligned)
     uint64_t learnt_buf;  // int32  [n_vars+1]   clause under construction
     uint64_t toclear;     // int32  [n_vars+1]   vars touched by analysis
     uint64_t lvl_stamp;   // uint32 [n_vars+2]   LBD computation
@@ -128,7 +131,8 @@ struct MsState {
     uint64_t slice_cycles;
     uint64_t n_steps;          // BCP steps (each propagates up to MS_MAX_GROUPS literals)
     uint64_t n_redo;           // literals re-queued because two groups met in one clause
-    uint64_t reserved[6];
+    uint64_t prof[10];         // per-phase cycle totals (profiling build only)
+    uint64_t reserved[2];
 };
 
 // Launch parameters of one slice.

@@ -142,7 +142,8 @@ struct mi355sat {
     // device
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf<uint32_t> d_cl_off, d_bin_off, d_tern_off;
+    DevBuf<MsClauseHdr> d_cl_hdr;
+    DevBuf<MsLitHdr> d_lit_hdr;
     DevBuf<int32_t> d_cl_lits, d_bin_lits, d_tern_owner;
     DevBuf<ms_int2> d_tern_pairs;
     bool lds_val = false;                      // assignment staged in LDS (2 bits/var)
@@ -170,11 +171,10 @@ struct Prepared {
     bool unsat = false;
     std::vector<int32_t> units;                 // internal literals fixed at level 0 (trail prefix)
     bool units_propagated = false;              // true if simplification ran (queue starts empty)
-    std::vector<uint32_t> cl_off{0};
-    std::vector<int32_t> cl_lits;
-    std::vector<uint32_t> bin_off;
+    std::vector<MsClauseHdr> cl_hdr;            // long clauses (>= 4 literals)
+    std::vector<int32_t> cl_lits;               // each clause 16-byte aligned, padded with its first literal
+    std::vector<MsLitHdr> lit_hdr;              // 2*n_vars
     std::vector<int32_t> bin_lits;
-    std::vector<uint32_t> tern_off;
     std::vector<ms_int2> tern_pairs;
     std::vector<int32_t> tern_owner;
 };
@@ -268,33 +268,38 @@ void prepare(const mi355sat& s, bool simplify, Prepared& P) {
         if (len == 2) bins.push_back({nl[no[c]], nl[no[c] + 1]});
         else if (len == 3) terns.push_back({nl[no[c]], nl[no[c] + 1], nl[no[c] + 2]});
         else {
+            P.cl_hdr.push_back(MsClauseHdr{(uint32_t)P.cl_lits.size(), (uint32_t)len});
             P.cl_lits.insert(P.cl_lits.end(), nl.begin() + no[c], nl.begin() + no[c + 1]);
-            P.cl_off.push_back((uint32_t)P.cl_lits.size());
+            while (P.cl_lits.size() % 4) P.cl_lits.push_back(nl[no[c]]);
         }
     }
+    for (int k = 0; k < 4; k++) P.cl_lits.push_back(0);  // a lane may read one 16-byte group past the last clause
     std::sort(bins.begin(), bins.end());
     bins.erase(std::unique(bins.begin(), bins.end()), bins.end());
-    P.bin_off.assign(2 * (size_t)nv + 1, 0);
-    for (auto& b : bins) { P.bin_off[(b.first ^ 1) + 1]++; P.bin_off[(b.second ^ 1) + 1]++; }
-    for (size_t i = 0; i < 2 * (size_t)nv; i++) P.bin_off[i + 1] += P.bin_off[i];
+    std::sort(terns.begin(), terns.end());
+    terns.erase(std::unique(terns.begin(), terns.end()), terns.end());
+    P.lit_hdr.assign(2 * (size_t)nv, MsLitHdr{0, 0, 0, 0});
+    for (auto& b : bins) { P.lit_hdr[b.first ^ 1].bin_n++; P.lit_hdr[b.second ^ 1].bin_n++; }
+    for (auto& c : terns)
+        for (int k = 0; k < 3; k++) P.lit_hdr[c[k] ^ 1].tern_n++;
+    {
+        uint32_t bo = 0, to = 0;
+        for (auto& hd : P.lit_hdr) { hd.bin_off = bo; bo += hd.bin_n; hd.tern_off = to; to += hd.tern_n; }
+    }
     P.bin_lits.resize(2 * bins.size());
     {
-        std::vector<uint32_t> fill(P.bin_off.begin(), P.bin_off.end() - 1);
+        std::vector<uint32_t> fill(2 * (size_t)nv);
+        for (size_t i = 0; i < fill.size(); i++) fill[i] = P.lit_hdr[i].bin_off;
         for (auto& b : bins) {
             P.bin_lits[fill[b.first ^ 1]++] = b.second;   // ~a -> b
             P.bin_lits[fill[b.second ^ 1]++] = b.first;   // ~b -> a
         }
     }
-    std::sort(terns.begin(), terns.end());
-    terns.erase(std::unique(terns.begin(), terns.end()), terns.end());
-    P.tern_off.assign(2 * (size_t)nv + 1, 0);
-    for (auto& c : terns)
-        for (int k = 0; k < 3; k++) P.tern_off[(c[k] ^ 1) + 1]++;
-    for (size_t i = 0; i < 2 * (size_t)nv; i++) P.tern_off[i + 1] += P.tern_off[i];
     P.tern_pairs.resize(3 * terns.size());
     P.tern_owner.resize(3 * terns.size());
     {
-        std::vector<uint32_t> fill(P.tern_off.begin(), P.tern_off.end() - 1);
+        std::vector<uint32_t> fill(2 * (size_t)nv);
+        for (size_t i = 0; i < fill.size(); i++) fill[i] = P.lit_hdr[i].tern_off;
         for (auto& c : terns)
             for (int k = 0; k < 3; k++) {
                 uint32_t e = fill[c[k] ^ 1]++;          // list of the literal that makes c[k] false
@@ -307,13 +312,13 @@ void prepare(const mi355sat& s, bool simplify, Prepared& P) {
 // ---- slab template -----------------------------------------------------------------
 void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_t script_cap,
                                std::vector<char>& tmpl) {
-    const uint32_t nv = P.n_vars, no = (uint32_t)P.cl_off.size() - 1;
+    const uint32_t nv = P.n_vars, no = (uint32_t)P.cl_hdr.size();
     MsLayout& L = s.L;
     memset(&L, 0, sizeof L);
     L.n_vars = nv;
     L.n_orig = no;
     // capacities
-    const uint64_t base_lits = P.cl_lits.size();
+    const uint64_t base_lits = P.cl_lits.size() + 3 * P.tern_pairs.size() / 3;
     L.learnt_cap = (uint32_t)std::min<uint64_t>(1u << 17, std::max<uint64_t>(1u << 15, 2 * (uint64_t)no + 4096));
     L.learnt_lit_cap = (uint32_t)std::min<uint64_t>(4u << 20, std::max<uint64_t>(1u << 20, 8 * base_lits));
     L.vm_cap = 3 * nv + 256;
@@ -323,7 +328,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     // 50% + 4 entries of slack; a list that outgrows its slot moves to the top of the bump pool and
     // the device compacts the pool again at every learnt-clause reduction (rebuild_watches).
     std::vector<uint32_t> cap(2 * (size_t)nv, 0);
-    for (uint32_t c = 0; c < no; c++) { cap[P.cl_lits[P.cl_off[c]] ^ 1]++; cap[P.cl_lits[P.cl_off[c] + 1] ^ 1]++; }
+    for (uint32_t c = 0; c < no; c++) { cap[P.cl_lits[P.cl_hdr[c].start] ^ 1]++; cap[P.cl_lits[P.cl_hdr[c].start + 1] ^ 1]++; }
     uint64_t pool_need = 0;
     std::vector<uint32_t> base(2 * (size_t)nv);
     for (size_t t = 0; t < cap.size(); t++) {
@@ -349,10 +354,8 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     place(L.vm_pos, 4 * (size_t)nv);
     place(L.vm_order, 4 * (size_t)L.vm_cap);
     place(L.wl, 8 * ((size_t)no + L.learnt_cap));
-    place(L.w_base, 4 * 2 * (size_t)nv);
-    place(L.w_size, 4 * 2 * (size_t)nv);
-    place(L.w_cap, 4 * 2 * (size_t)nv);
-    place(L.lc_off, 4 * ((size_t)L.learnt_cap + 1));
+    place(L.whdr, sizeof(MsWatchHdr) * 2 * (size_t)nv);
+    place(L.lc_hdr, sizeof(MsClauseHdr) * (size_t)L.learnt_cap);
     place(L.lc_lbd, 4 * (size_t)L.learnt_cap);
     place(L.learnt_buf, 4 * ((size_t)nv + 1));
     place(L.toclear, 4 * ((size_t)nv + 1));
@@ -394,16 +397,14 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     int32_t* vm_order = (int32_t*)(T + L.vm_order);
     for (uint32_t v = 0; v < nv; v++) { vm_order[nv - 1 - v] = (int32_t)v; vm_pos[v] = (int32_t)(nv - 1 - v); }
     int2* wl = (int2*)(T + L.wl);
-    uint32_t* w_base = (uint32_t*)(T + L.w_base);
-    uint32_t* w_size = (uint32_t*)(T + L.w_size);
-    uint32_t* w_cap = (uint32_t*)(T + L.w_cap);
+    MsWatchHdr* whdr = (MsWatchHdr*)(T + L.whdr);
     int2* pool = (int2*)(T + L.pool);
-    for (size_t t = 0; t < cap.size(); t++) { w_base[t] = base[t]; w_cap[t] = cap[t]; w_size[t] = 0; }
+    for (size_t t = 0; t < cap.size(); t++) whdr[t] = MsWatchHdr{base[t], 0, cap[t], 0};
     for (uint32_t c = 0; c < no; c++) {
-        int32_t a = P.cl_lits[P.cl_off[c]], b = P.cl_lits[P.cl_off[c] + 1];
+        int32_t a = P.cl_lits[P.cl_hdr[c].start], b = P.cl_lits[P.cl_hdr[c].start + 1];
         wl[c] = make_int2(a, b);
-        pool[w_base[a ^ 1] + w_size[a ^ 1]++] = make_int2((int)c, b);
-        pool[w_base[b ^ 1] + w_size[b ^ 1]++] = make_int2((int)c, a);
+        pool[whdr[a ^ 1].base + whdr[a ^ 1].size++] = make_int2((int)c, b);
+        pool[whdr[b ^ 1].base + whdr[b ^ 1].size++] = make_int2((int)c, a);
     }
 }
 
@@ -414,20 +415,18 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     std::vector<char> tmpl;
     build_layout_and_template(s, P, assump_cap, script_cap, tmpl);
     s.n_vars = P.n_vars;
-    s.d_cl_off.upload(P.cl_off, s.stream);
+    s.d_cl_hdr.upload(P.cl_hdr.empty() ? std::vector<MsClauseHdr>{MsClauseHdr{0, 0}} : P.cl_hdr, s.stream);
     s.d_cl_lits.upload(P.cl_lits, s.stream);
-    s.d_bin_off.upload(P.bin_off, s.stream);
-    s.d_bin_lits.upload(P.bin_lits, s.stream);
-    s.d_tern_off.upload(P.tern_off, s.stream);
+    s.d_lit_hdr.upload(P.lit_hdr.empty() ? std::vector<MsLitHdr>{MsLitHdr{0, 0, 0, 0}} : P.lit_hdr, s.stream);
+    s.d_bin_lits.upload(P.bin_lits.empty() ? std::vector<int32_t>{0} : P.bin_lits, s.stream);
     s.d_tern_pairs.upload(P.tern_pairs.empty() ? std::vector<ms_int2>{ms_int2{0, 0}} : P.tern_pairs, s.stream);
     s.d_tern_owner.upload(P.tern_owner.empty() ? std::vector<int32_t>{0} : P.tern_owner, s.stream);
     s.sh.n_vars = P.n_vars;
-    s.sh.n_orig = (uint32_t)P.cl_off.size() - 1;
-    s.sh.cl_off = s.d_cl_off.p;
+    s.sh.n_orig = (uint32_t)P.cl_hdr.size();
+    s.sh.cl_hdr = s.d_cl_hdr.p;
     s.sh.cl_lits = s.d_cl_lits.p;
-    s.sh.bin_off = s.d_bin_off.p;
+    s.sh.lit_hdr = s.d_lit_hdr.p;
     s.sh.bin_lits = s.d_bin_lits.p;
-    s.sh.tern_off = s.d_tern_off.p;
     s.sh.tern_pairs = s.d_tern_pairs.p;
     s.sh.tern_owner = s.d_tern_owner.p;
     // assignment in LDS (2 bits per variable) when it leaves room for >= 5 waves per CU
@@ -508,6 +507,15 @@ void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
     o.n_deq += props; o.n_watch += nw; o.n_cl_lit += ncl; o.n_move += nm; o.n_enq += ne;
     o.learnts = learnts; o.learnt_literals = llits;
     o.bcp_steps += steps; o.bcp_requeued += redo;
+    for (int i = 0; i < 6; i++) o.reserved[i] = 0;
+    uint64_t prof[10] = {0}, cyc = 0;
+    for (auto& st : sts) { for (int i = 0; i < 10; i++) prof[i] += st.prof[i]; cyc += st.slice_cycles; }
+    if (prof[0] && s.opts.verbose) {
+        static const char* nm[] = {"offsets", "binary", "ternary", "long", "close", "analyze", "backjump+learn", "decide", "reduce"};
+        fprintf(stderr, "[mi355sat] phase cycle shares of %.3e worker-cycles:", (double)cyc);
+        for (int i = 0; i < 9; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)prof[i] / (double)cyc);
+        fprintf(stderr, "\n");
+    }
 }
 
 void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_t n_vars_out) {
@@ -736,8 +744,8 @@ void mi355sat_free(mi355sat* s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     delete s->sweep;
-    s->d_cl_off.release(); s->d_bin_off.release(); s->d_cl_lits.release(); s->d_bin_lits.release();
-    s->d_tern_off.release(); s->d_tern_pairs.release(); s->d_tern_owner.release();
+    s->d_cl_hdr.release(); s->d_lit_hdr.release(); s->d_cl_lits.release(); s->d_bin_lits.release();
+    s->d_tern_pairs.release(); s->d_tern_owner.release();
     s->d_template.release(); s->d_slabs.release(); s->d_states.release(); s->d_any_done.release();
     s->d_assump.release(); s->d_script.release(); s->d_assump_off.release(); s->d_script_off.release();
     if (s->stop_flag) (void)hipHostFree(s->stop_flag);
