@@ -35,6 +35,11 @@
 
 typedef unsigned long long u64;
 
+// Register budget of the search kernel: 4 waves per SIMD = 16 workers per CU = 4096 per GPU.
+#ifndef MS_SEARCH_WAVES_PER_SIMD
+#define MS_SEARCH_WAVES_PER_SIMD 4
+#endif
+
 // Optional per-phase cycle stamps (diagnostic build only: make prof -> libmi355sat_prof.so).
 // Phase totals land in MsState::reserved[0..5] + n_prof[...] and are never read by the solver.
 #ifdef MS_PROFILE
@@ -535,7 +540,7 @@ DEV void new_decision_level(Wk& w, const MsShared& sh, const MsLayout& L) {
 // vm_order[0..vm_end) holds variables; the entry of v is live iff vm_pos[v] is its
 // index.  Later index = more recently bumped.  vm_search: every live entry above
 // it is assigned.
-DEV_COLD void vm_compact(Wk& w, const MsShared& sh, const MsLayout& L) {
+DEV void vm_compact(Wk& w, const MsShared& sh, const MsLayout& L) {
     int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
     int32_t* vm_pos = WK_PTR(int32_t, w, L, vm_pos);
     int j = 0;
@@ -620,7 +625,7 @@ DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, uint8_t* se
     path_c += popc64(cm);
 }
 
-DEV_COLD Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
+DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
     uint8_t* seen = WK_PTR(uint8_t, w, L, seen);
     int32_t* toclear = WK_PTR(int32_t, w, L, toclear);
     int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
@@ -797,7 +802,7 @@ DEV Learnt analyze_call(Wk& w, const MsShared& sh, const MsLayout& L) {
 // hole behind.  The rebuild lays every list out again, densely, straight from the
 // per-clause watched-literal pairs (no read of the old pool): count, exclusive scan
 // over the 2*n_vars lists (wave prefix sums), fill.  Runs at a propagation fixpoint.
-DEV_COLD void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
+DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
     MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
     int2* pool = WKA(int2, pool);
     const int2* wl = WKA(int2, wl);
@@ -843,7 +848,7 @@ DEV_COLD void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
 // since the last reduction with lbd <= 6; of the rest drop the worse half by an
 // LBD cut-off (histogram in LDS, no sort), breaking ties by age.
 template <bool LV>
-DEV_COLD void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
+DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
     volatile uint32_t* hist = w.hist;
     MsClauseHdr* lc_hdr = WK_PTR(MsClauseHdr, w, L, lc_hdr);
     uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
@@ -970,7 +975,7 @@ DEV void rebuild_watches_call(Wk& w, const MsShared& sh, const MsLayout& L) {
 template <bool LV>
 DEV int add_learnt(Wk& w, const MsShared& sh, const MsLayout& L, int n, uint32_t lbd) {
     if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n + 8 > L.learnt_lit_cap) {
-        reduce_db_call<LV>(w, sh, L);  // store full before the scheduled reduction: reduce now (state is consistent here)
+        reduce_db<LV>(w, sh, L);  // store full before the scheduled reduction: reduce now (state is consistent here)
         if (w.status != MS_ST_RUNNING) return -1;
         if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n + 8 > L.learnt_lit_cap) {
             w.status = MS_ST_ERR_LEARNT;
@@ -1054,12 +1059,101 @@ DEV void wk_store(Wk& w, const MsShared& sh, const MsLayout& L, u64 cycles) {
 }
 
 // ---- the search kernel -------------------------------------------------------------
+// Restart / reduction bookkeeping of one worker during a slice.  It is only touched by the two
+// cold-path functions below, so it can live in scratch memory.
+struct LoopState {
+    u64 conflicts, restarts, reduce_dbs, lbdq_sum, lbd_total, next_reduce, learnt_total, learnt_lits_total;
+    uint32_t lbdq_n, lbdq_i;
+    double trail_avg;
+    int n_assumps;
+    volatile uint32_t* lbdq;   // LDS ring of the last MS_LBDQ learnt-clause LBDs
+};
+
+// A conflict was found by propagate(): learn, backjump, assert (Glucose `search` conflict branch).
+template <bool LV>
+DEV_COLD void on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls) {
+    PROF_DECL
+    ls.conflicts++;
+    if (w.n_levels == 0) { w.status = MS_ST_UNSAT; return; }
+    // Glucose restart blocking: a trail much longer than its running average
+    // (an exponential average stands in for the 5000-entry queue)
+    ls.trail_avg += ((double)w.trail_n - ls.trail_avg) * (1.0 / 5000.0);
+    if (ls.conflicts > 10000 && ls.lbdq_n == MS_LBDQ && (double)w.trail_n > 1.4 * ls.trail_avg) {
+        ls.lbdq_n = 0; ls.lbdq_i = 0; ls.lbdq_sum = 0;
+    }
+    Learnt lr = analyze(w, sh, L);
+    PROF_MARK(PF_ANALYZE);
+    if (w.status != MS_ST_RUNNING) return;
+    const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
+    cancel_until<LV>(w, sh, L, lr.bt_level);
+    if (lr.n == 1) {
+        int l0 = uni(learnt_buf[0]);  // unit learnt: bt_level is 0
+        if (lit_value<LV>(w, sh, L, l0) == MS_VAL_FALSE) { w.status = MS_ST_UNSAT; return; }
+        enqueue_uniform<LV>(w, sh, L, l0, MS_REASON_NONE);
+    } else {
+        int cref = add_learnt<LV>(w, sh, L, lr.n, lr.lbd);
+        if (cref < 0) return;
+        enqueue_uniform<LV>(w, sh, L, uni(learnt_buf[0]), cref);
+    }
+    PROF_MARK(PF_BACKJUMP);
+    ls.learnt_total++;
+    ls.learnt_lits_total += (u64)lr.n;
+    ls.lbdq_sum += lr.lbd;
+    if (ls.lbdq_n == MS_LBDQ) ls.lbdq_sum -= ls.lbdq[ls.lbdq_i]; else ls.lbdq_n++;
+    lds_fence();
+    if (w.lane == 0) ls.lbdq[ls.lbdq_i] = lr.lbd;
+    lds_fence();
+    ls.lbdq_i = (ls.lbdq_i + 1) % MS_LBDQ;
+    ls.lbd_total += lr.lbd;
+}
+
+// BCP reached a fixpoint without conflict: restart? reduce? then assumptions / next decision.
+template <bool LV>
+DEV_COLD void on_fixpoint(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls, uint32_t reduce_first,
+                          uint32_t reduce_inc) {
+    PROF_DECL
+    if (ls.lbdq_n == MS_LBDQ && ((double)ls.lbdq_sum / MS_LBDQ) * 0.8 > (double)ls.lbd_total / (double)ls.conflicts) {
+        ls.lbdq_n = 0; ls.lbdq_i = 0; ls.lbdq_sum = 0;
+        ls.restarts++;
+        cancel_until<LV>(w, sh, L, 0);
+    }
+    if (ls.conflicts >= ls.next_reduce || w.n_learnts > L.learnt_cap - L.learnt_cap / 8 ||
+        w.lc_lits_n > L.learnt_lit_cap - L.learnt_lit_cap / 8) {
+        ls.reduce_dbs++;
+        ls.next_reduce = ls.conflicts + reduce_first + (u64)reduce_inc * ls.reduce_dbs;
+        reduce_db<LV>(w, sh, L);
+    }
+    if (w.pool_top > L.pool_cap - L.pool_cap / 4) rebuild_watches(w, sh, L);  // pool running low: collect holes
+    PROF_MARK(PF_REDUCE);
+    if (w.status != MS_ST_RUNNING) return;
+    const int32_t* assumps = WK_PTR(int32_t, w, L, assumps);
+    int next = -1;
+    while (w.n_levels < ls.n_assumps) {
+        int a = uni(assumps[w.n_levels]);
+        int va = lit_value<LV>(w, sh, L, a);
+        if (va == MS_VAL_TRUE) new_decision_level(w, sh, L);      // dummy level
+        else if (va == MS_VAL_FALSE) { w.status = MS_ST_UNSAT; return; }
+        else { next = a; break; }
+    }
+    if (next < 0) {
+        int v = pick_branch_var<LV>(w, sh, L);
+        if (v < 0) { w.status = MS_ST_SAT; return; }
+        w.c_dec++;
+        next = uni(2 * v + (int)WK_PTR(uint8_t, w, L, phase)[v]);
+    }
+    new_decision_level(w, sh, L);
+    enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);
+    PROF_MARK(PF_DECIDE);
+}
+
 // grid = n_workers blocks of 64 threads.  Runs each worker until it has a verdict,
 // or has spent its slice (conflicts / propagations), or the host / another worker
 // raised a stop flag.  All state is persisted in the slab, so the host simply
 // relaunches the kernel to continue.  LV = assignment staged in (dynamic) LDS.
+// The loop body is propagate() plus two cold calls working on a scratch copy of the
+// worker context, so the register allocation is that of the BCP loop.
 template <bool LV>
-__global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
+__global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
     __shared__ uint32_t s_hist[64];
@@ -1074,58 +1168,25 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
     if (w.lane == 0) s_ov = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     MsState* st = WKA(MsState, state);
-    volatile uint32_t* lbdq = s_lbdq;
-    if (w.lane < MS_LBDQ) lbdq[w.lane] = st->lbdq[w.lane];
+    if (w.lane < MS_LBDQ) s_lbdq[w.lane] = st->lbdq[w.lane];
     lds_fence();
     const u64 t0 = __builtin_readcyclecounter();
-    const int n_assumps = st->n_assumps;
-    const int32_t* assumps = WK_PTR(int32_t, w, L, assumps);
-    const uint8_t* phase = WK_PTR(uint8_t, w, L, phase);
-    const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
-    // restart / reduce state: uniform registers for the slice
-    u64 conflicts = st->conflicts, restarts = st->restarts, reduce_dbs = st->reduce_dbs;
-    u64 lbdq_sum = st->lbdq_sum, lbd_total = st->lbd_total, next_reduce = st->next_reduce;
-    uint32_t lbdq_n = st->lbdq_n, lbdq_i = st->lbdq_i;
-    double trail_avg = st->trail_avg;
-    u64 learnt_total = st->learnt_total, learnt_lits_total = st->learnt_lits_total;
+    LoopState ls;
+    ls.conflicts = st->conflicts; ls.restarts = st->restarts; ls.reduce_dbs = st->reduce_dbs;
+    ls.lbdq_sum = st->lbdq_sum; ls.lbd_total = st->lbd_total; ls.next_reduce = st->next_reduce;
+    ls.learnt_total = st->learnt_total; ls.learnt_lits_total = st->learnt_lits_total;
+    ls.lbdq_n = st->lbdq_n; ls.lbdq_i = st->lbdq_i; ls.trail_avg = st->trail_avg;
+    ls.n_assumps = st->n_assumps; ls.lbdq = s_lbdq;
+    MsShared sc = sh;     // private copies for the cold calls (their address is taken)
+    MsLayout lc = L;
     uint32_t slice_confl = 0;
     const bool entered_running = w.status == MS_ST_RUNNING;
     while (w.status == MS_ST_RUNNING) {
         if (propagate<LV>(w, sh, L)) {
-            // ---------------- conflict
+            Wk t = w;
+            on_conflict<LV>(t, sc, lc, ls);
+            w = t;
             slice_confl++;
-            conflicts++;
-            if (w.n_levels == 0) { w.status = MS_ST_UNSAT; break; }
-            // Glucose restart blocking: a trail much longer than its running average
-            // (an exponential average stands in for the 5000-entry queue)
-            trail_avg += ((double)w.trail_n - trail_avg) * (1.0 / 5000.0);
-            if (conflicts > 10000 && lbdq_n == MS_LBDQ && (double)w.trail_n > 1.4 * trail_avg) {
-                lbdq_n = 0; lbdq_i = 0; lbdq_sum = 0;
-            }
-            PROF_DECL
-            Learnt lr = analyze_call(w, sh, L);
-            PROF_MARK(PF_ANALYZE);
-            if (w.status != MS_ST_RUNNING) break;
-            cancel_until<LV>(w, sh, L, lr.bt_level);
-            if (lr.n == 1) {
-                int l0 = uni(learnt_buf[0]);  // unit learnt: bt_level is 0
-                if (lit_value<LV>(w, sh, L, l0) == MS_VAL_FALSE) { w.status = MS_ST_UNSAT; break; }
-                enqueue_uniform<LV>(w, sh, L, l0, MS_REASON_NONE);
-            } else {
-                int cref = add_learnt<LV>(w, sh, L, lr.n, lr.lbd);
-                if (cref < 0) break;
-                enqueue_uniform<LV>(w, sh, L, uni(learnt_buf[0]), cref);
-            }
-            PROF_MARK(PF_BACKJUMP);
-            learnt_total++;
-            learnt_lits_total += (u64)lr.n;
-            lbdq_sum += lr.lbd;
-            if (lbdq_n == MS_LBDQ) lbdq_sum -= lbdq[lbdq_i]; else lbdq_n++;
-            lds_fence();
-            if (w.lane == 0) lbdq[lbdq_i] = lr.lbd;
-            lds_fence();
-            lbdq_i = (lbdq_i + 1) % MS_LBDQ;
-            lbd_total += lr.lbd;
             if (slice_confl >= prm.slice_conflicts) break;
             if ((slice_confl & 63) == 0) {
                 if (*prm.stop_flag) break;
@@ -1134,51 +1195,19 @@ __global__ __launch_bounds__(MS_WAVE) void ms_search_kernel(MsShared sh, MsLayou
         } else {
             if (w.status != MS_ST_RUNNING) break;
             if (prm.slice_props && w.c_props >= prm.slice_props) break;
-            // ---------------- no conflict: restart? reduce? decide
-            PROF_DECL
-            if (lbdq_n == MS_LBDQ && ((double)lbdq_sum / MS_LBDQ) * 0.8 > (double)lbd_total / (double)conflicts) {
-                lbdq_n = 0; lbdq_i = 0; lbdq_sum = 0;
-                restarts++;
-                cancel_until<LV>(w, sh, L, 0);
-            }
-            if (conflicts >= next_reduce || w.n_learnts > L.learnt_cap - L.learnt_cap / 8 ||
-                w.lc_lits_n > L.learnt_lit_cap - L.learnt_lit_cap / 8) {
-                reduce_dbs++;
-                next_reduce = conflicts + prm.reduce_first + (u64)prm.reduce_inc * reduce_dbs;
-                reduce_db_call<LV>(w, sh, L);
-            }
-            if (w.pool_top > L.pool_cap - L.pool_cap / 4) rebuild_watches_call(w, sh, L);
-            PROF_MARK(PF_REDUCE);  // pool running low: collect holes
-            if (w.status != MS_ST_RUNNING) break;
-            int next = -1;
-            bool refuted = false;
-            while (w.n_levels < n_assumps) {
-                int a = uni(assumps[w.n_levels]);
-                int va = lit_value<LV>(w, sh, L, a);
-                if (va == MS_VAL_TRUE) new_decision_level(w, sh, L);      // dummy level
-                else if (va == MS_VAL_FALSE) { refuted = true; break; }
-                else { next = a; break; }
-            }
-            if (refuted) { w.status = MS_ST_UNSAT; break; }
-            if (next < 0) {
-                int v = pick_branch_var<LV>(w, sh, L);
-                if (v < 0) { w.status = MS_ST_SAT; break; }
-                w.c_dec++;
-                next = uni(2 * v + (int)phase[v]);
-            }
-            new_decision_level(w, sh, L);
-            enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);
-            PROF_MARK(PF_DECIDE);
+            Wk t = w;
+            on_fixpoint<LV>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc);
+            w = t;
         }
     }
     if (entered_running && w.status != MS_ST_RUNNING && w.lane == 0 && prm.any_done) atomicExch(prm.any_done, 1);
     lds_fence();
-    if (w.lane < MS_LBDQ) st->lbdq[w.lane] = lbdq[w.lane];
+    if (w.lane < MS_LBDQ) st->lbdq[w.lane] = s_lbdq[w.lane];
     if (w.lane == 0) {
-        st->conflicts = conflicts; st->restarts = restarts; st->reduce_dbs = reduce_dbs;
-        st->lbdq_sum = lbdq_sum; st->lbd_total = lbd_total; st->next_reduce = next_reduce;
-        st->lbdq_n = lbdq_n; st->lbdq_i = lbdq_i; st->trail_avg = trail_avg;
-        st->learnt_total = learnt_total; st->learnt_lits_total = learnt_lits_total;
+        st->conflicts = ls.conflicts; st->restarts = ls.restarts; st->reduce_dbs = ls.reduce_dbs;
+        st->lbdq_sum = ls.lbdq_sum; st->lbd_total = ls.lbd_total; st->next_reduce = ls.next_reduce;
+        st->lbdq_n = ls.lbdq_n; st->lbdq_i = ls.lbdq_i; st->trail_avg = ls.trail_avg;
+        st->learnt_total = ls.learnt_total; st->learnt_lits_total = ls.learnt_lits_total;
     }
     wk_store<LV>(w, sh, L, __builtin_readcyclecounter() - t0);
 }
