@@ -4,8 +4,9 @@ BASELINE.json headline workload (rect 64x64, decreasing-k sweep at the
 first-UNSAT bound, default platform set).
 
 One *step* = one slice of the search kernel over this GPU's batch of (k, seed)
-instances: every worker (one wavefront) advances its own CDCL search by
-`--slice` conflicts.  Inputs (clause database, worker slabs) are resident in HBM
+instances: every worker (one wavefront) advances its own CDCL search for
+`--slice-ms` milliseconds of device time (time-bounded so that all workers stop
+together; a conflict-bounded slice is dominated by its slowest worker).  Inputs (clause database, worker slabs) are resident in HBM
 before the timed region.  Multi-GPU: one process per GPU; the (k, seed) instances
 are independent, so ranks shard the seeds with no data-path collective and only
 exchange the SAT/UNSAT cut (min SAT count, max UNSAT k: one tiny all-reduce per
@@ -37,8 +38,8 @@ def main():
     ap.add_argument("--size", type=int, default=64, help="rect SIZE x SIZE")
     ap.add_argument("--k-lo", type=int, default=44)
     ap.add_argument("--k-hi", type=int, default=51)
-    ap.add_argument("--workers", type=int, default=2048, help="wavefront workers per GPU")
-    ap.add_argument("--slice", type=int, default=100, help="conflicts per worker per step")
+    ap.add_argument("--workers", type=int, default=3072, help="wavefront workers per GPU (12 per CU)")
+    ap.add_argument("--slice-ms", type=int, default=250, help="device time of one step (one kernel launch)")
     ap.add_argument("--cpu-conflicts", type=int, default=20000, help="conflict budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--platforms", default="default", choices=["default", "1x1"])
@@ -70,7 +71,7 @@ def main():
     assumption_sets = [([-int(outs[k])] if k < args.k_hi else []) for k in ks]
     workers = max(len(ks), args.workers // len(ks) * len(ks))
 
-    solver = Mi355Sat(device=local_rank, workers=workers, slice_conflicts=args.slice, seed=1000 + rank)
+    solver = Mi355Sat(device=local_rank, workers=workers, slice_ms=args.slice_ms, seed=1000 + rank)
     solver.add_cnf(cnf.lits, cnf.offsets)
     solver.reserve(cnf.n_vars)
     solver.sweep_begin(assumption_sets)  # upload + replicate: everything resident in HBM from here on
@@ -154,7 +155,7 @@ def main():
             "config": {"workload": f"rect {n} {n} k-sweep at the first-UNSAT bound: at-most-k for k={args.k_hi}..{args.k_lo}, "
                                    f"{args.platforms} platforms, one totalizer CNF shared by all k",
                        "vars": int(cnf.n_vars), "clauses": int(cnf.n_clauses), "literals": int(len(cnf.lits)),
-                       "workers_per_gpu": workers, "instances_per_gpu": len(ks), "slice_conflicts": args.slice,
+                       "workers_per_gpu": workers, "instances_per_gpu": len(ks), "slice_ms": args.slice_ms,
                        "parallelism": f"{world} GPU(s) x {workers} wavefront workers, seeds sharded over ranks"},
             "conflicts_per_s": total_confl / max_dt,
             "decided_instances": int(decided),

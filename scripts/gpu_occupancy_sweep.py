@@ -4,12 +4,22 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from timberborn_support_solver_amd import *
+import ctypes
 size, k, slc = 64, 46, 50
 grid = WorldGrid.rect(size, size)
 enc = Encoding.encode(PLATFORMS_DEFAULT, grid)
 cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
-for lds, W in [(1, 1280), (1, 1536), (-1, 1280), (-1, 2048), (-1, 3072), (-1, 4096), (-1, 6144)]:
-    s = Mi355Sat(workers=W, slice_conflicts=slc, conflict_budget=W * slc, lds_val=lds)
+cases = []
+for occ in (2, 3, 4):
+    for W in (1280, occ * 1024, occ * 1536):
+        cases.append((occ, -1, W))
+cases += [(2, 1, 1536), (4, 1, 1536)]
+libs = {}
+for occ, lds, W in cases:
+    if occ not in libs:
+        libs[occ] = ctypes.CDLL(os.path.join(ROOT, "timberborn_support_solver_amd", f"libmi355sat_occ{occ}.so"))
+    print(f"occ{occ}", end=" ")
+    s = Mi355Sat(workers=W, slice_ms=400, conflict_budget=1, lds_val=lds, _lib_override=libs[occ])
     s.add_cnf(cnf.lits, cnf.offsets)
     r = s.solve()
     st = s.stats()

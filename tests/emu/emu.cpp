@@ -7,8 +7,10 @@ double emu_now() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+unsigned long long emu_ticks_100mhz() { return (unsigned long long)(emu_now() * 1e8); }
+
 namespace emu {
-thread_local Idx t_threadIdx{0, 0, 0}, t_blockIdx{0, 0, 0}, t_blockDim{1, 1, 1};
+thread_local Idx t_threadIdx{0, 0, 0}, t_blockIdx{0, 0, 0}, t_blockDim{1, 1, 1}, t_gridDim{1, 1, 1};
 
 namespace {
 constexpr int kLanes = 64;
@@ -63,8 +65,10 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     g = &sched;
     g->body = &body;
     t_blockDim = Idx{block.x, block.y, block.z};
+    t_gridDim = Idx{grid.x, grid.y, grid.z};
+    for (unsigned by = 0; by < grid.y; by++)
     for (unsigned b = 0; b < grid.x; b++) {
-        t_blockIdx = Idx{b, 0, 0};
+        t_blockIdx = Idx{b, by, 0};
         if (block.x != (unsigned)kLanes) {
             g->wave_mode = false;
             for (unsigned t = 0; t < block.x; t++) {

@@ -38,11 +38,12 @@
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct int2 { int x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline int2 make_int2(int a, int b) { return int2{a, b}; }
 
 namespace emu {
 struct Idx { unsigned x, y, z; };
-extern thread_local Idx t_threadIdx, t_blockIdx, t_blockDim;
+extern thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 void collective_begin(uint64_t contribution, int site);   // publish + rendezvous
 uint64_t collective_read(int lane);                        // value published by `lane`
 void fence_rendezvous();
@@ -51,6 +52,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 #define threadIdx (emu::t_threadIdx)
 #define blockIdx (emu::t_blockIdx)
 #define blockDim (emu::t_blockDim)
+#define gridDim (emu::t_gridDim)
 
 using std::max;
 using std::min;
@@ -86,6 +88,8 @@ static inline int __builtin_amdgcn_readfirstlane(int v) {
 }
 #define __builtin_amdgcn_fence(order, scope) emu::fence_rendezvous()
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+unsigned long long emu_ticks_100mhz();
+#define __builtin_amdgcn_s_memrealtime() emu_ticks_100mhz()
 #ifndef __clang__
 static inline unsigned long long __builtin_readcyclecounter() { return __builtin_ia32_rdtsc(); }
 #endif

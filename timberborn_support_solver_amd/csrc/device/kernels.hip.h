@@ -35,9 +35,10 @@
 
 typedef unsigned long long u64;
 
-// Register budget of the search kernel: 4 waves per SIMD = 16 workers per CU = 4096 per GPU.
+// Register budget of the search kernel: 3 waves per SIMD = 12 workers per CU = 3072 per GPU
+// (measured: 4 per SIMD forces spills into the BCP loop and is slower in aggregate).
 #ifndef MS_SEARCH_WAVES_PER_SIMD
-#define MS_SEARCH_WAVES_PER_SIMD 4
+#define MS_SEARCH_WAVES_PER_SIMD 3
 #endif
 
 // Optional per-phase cycle stamps (diagnostic build only: make prof -> libmi355sat_prof.so).
@@ -1181,7 +1182,9 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     MsLayout lc = L;
     uint32_t slice_confl = 0;
     const bool entered_running = w.status == MS_ST_RUNNING;
+    const u64 tick0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
     while (w.status == MS_ST_RUNNING) {
+        if (prm.slice_ticks && __builtin_amdgcn_s_memrealtime() - tick0 >= prm.slice_ticks) break;
         if (propagate<LV>(w, sh, L)) {
             Wk t = w;
             on_conflict<LV>(t, sc, lc, ls);

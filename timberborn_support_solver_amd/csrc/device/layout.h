@@ -140,6 +140,7 @@ struct MsParams {
     uint32_t n_workers;
     uint32_t slice_conflicts;      // stop the slice after this many conflicts per worker
     uint64_t slice_props;          // ... or this many propagations (0 = unlimited)
+    uint64_t slice_ticks;          // ... or this much wall time, in 10 ns ticks of the 100 MHz counter (0 = unlimited)
     const volatile int32_t* stop_flag;  // pinned host int: nonzero -> leave the slice early
     int32_t stop_on_any;           // leave when any worker has finished (any_done)
     int32_t max_groups;            // 1..MS_MAX_GROUPS queue literals per BCP step

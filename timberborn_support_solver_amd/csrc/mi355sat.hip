@@ -91,6 +91,19 @@ __global__ void ms_customize_kernel(MsLayout L, char* slabs, uint32_t n_workers,
     }
 }
 
+// Replicates the template slab (its head and the initially used part of the watch pool) into
+// every worker slab with 16-byte copies: one launch instead of two memcpys per worker.
+__global__ void ms_replicate_kernel(const char* tmpl, char* slabs, uint64_t slab_bytes, uint64_t head_bytes,
+                                    uint64_t pool_off, uint64_t pool_bytes) {
+    char* dst = slabs + (size_t)blockIdx.y * slab_bytes;
+    const uint64_t n_head = head_bytes / 16, n_pool = (pool_bytes + 15) / 16;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_head + n_pool; i += stride) {
+        const uint64_t off = i < n_head ? i * 16 : pool_off + (i - n_head) * 16;
+        *(uint4*)(dst + off) = *(const uint4*)(tmpl + off);
+    }
+}
+
 __global__ void ms_gather_states_kernel(MsLayout L, const char* slabs, uint32_t n_workers, MsState* out) {
     const uint32_t wid = blockIdx.x * blockDim.x + threadIdx.x;
     if (wid >= n_workers) return;
@@ -429,9 +442,10 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.sh.bin_lits = s.d_bin_lits.p;
     s.sh.tern_pairs = s.d_tern_pairs.p;
     s.sh.tern_owner = s.d_tern_owner.p;
-    // assignment in LDS (2 bits per variable) when it leaves room for >= 5 waves per CU
+    // assignment in LDS (2 bits per variable) when it still leaves room for 12 waves per CU
+    // (measured on rect 64x64: 12 waves/CU with the assignment in HBM beat 6 waves/CU with it in LDS)
     s.lds_val_bytes = ((P.n_vars + 15) / 16) * 4;
-    s.lds_val = s.opts.lds_val == 1 || (s.opts.lds_val == 0 && s.lds_val_bytes <= 28 * 1024);
+    s.lds_val = s.opts.lds_val == 1 || (s.opts.lds_val == 0 && s.lds_val_bytes <= 10 * 1024);
     if (s.lds_val_bytes > 150 * 1024) s.lds_val = false;
     // worker count limited by free HBM
     size_t free_b = 0, total_b = 0;
@@ -458,12 +472,9 @@ void reset_workers(mi355sat& s) {
     const size_t head = L.lc_lits;  // everything before the learnt literal store
     const MsState* tst = nullptr;
     (void)tst;
-    for (uint32_t w = 0; w < s.n_workers; w++) {
-        char* dst = s.d_slabs.p + (size_t)w * L.slab_bytes;
-        HIPCHK(hipMemcpyAsync(dst, s.d_template.p, head, hipMemcpyDeviceToDevice, s.stream));
-        HIPCHK(hipMemcpyAsync(dst + L.pool, s.d_template.p + L.pool, 8 * (size_t)s.pool_init,
-                              hipMemcpyDeviceToDevice, s.stream));
-    }
+    hipLaunchKernelGGL(ms_replicate_kernel, dim3(64, s.n_workers), dim3(256), 0, s.stream, (const char*)s.d_template.p,
+                       s.d_slabs.p, (uint64_t)L.slab_bytes, (uint64_t)head, (uint64_t)L.pool, (uint64_t)(8 * s.pool_init));
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(s.d_any_done.p, 0, sizeof(int32_t), s.stream));
 }
 
@@ -533,8 +544,11 @@ struct SliceResult { float ms; };
 SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any) {
     MsParams prm{};
     prm.n_workers = s.n_workers;
-    prm.slice_conflicts = s.opts.slice_conflicts > 0 ? (uint32_t)s.opts.slice_conflicts : 2000u;
+    prm.slice_conflicts = s.opts.slice_conflicts > 0 ? (uint32_t)s.opts.slice_conflicts : 0xffffffffu;
     prm.slice_props = 0;
+    // default: time-bounded slices (all workers stop together; no straggler tail), 20 ms
+    const int slice_ms = s.opts.slice_ms > 0 ? s.opts.slice_ms : (s.opts.slice_conflicts > 0 ? 0 : 20);
+    prm.slice_ticks = slice_ms > 0 ? (uint64_t)slice_ms * 100000ull : 0;
     prm.stop_flag = s.stop_flag;
     prm.stop_on_any = stop_on_any ? 1 : 0;
     prm.max_groups = s.opts.max_groups > 0 ? s.opts.max_groups : MS_MAX_GROUPS;
@@ -599,7 +613,9 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     uint32_t max_assumps = 0;
     for (uint32_t i = 0; i < n_instances; i++)
         max_assumps = std::max<uint32_t>(max_assumps, (uint32_t)(assump_off[i + 1] - assump_off[i]));
-    uint32_t want = s.opts.workers > 0 ? (uint32_t)s.opts.workers : 256u;
+    // default worker count: the resident capacity (12 wavefronts on each of 256 CUs) for large formulas,
+    // one wavefront per CU for small ones (their slabs are replicated per solve; keep that cheap)
+    uint32_t want = s.opts.workers > 0 ? (uint32_t)s.opts.workers : (s.offs.size() > 100000 ? 3072u : 256u);
     if (want < n_instances) want = n_instances;
     want = want / n_instances * n_instances;
     std::vector<int32_t> a_int(assump.size());
