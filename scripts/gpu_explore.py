@@ -10,7 +10,7 @@ def run(terrain, pset, k, workers, slice_conflicts=500, cpu=True, budget=0, **kw
     grid = WorldGrid.rect(w, h)
     enc = Encoding.encode(PLATFORMS_DEFAULT if pset == "default" else [(1, 1)], grid)
     cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
-    s = Mi355Sat(workers=workers, slice_conflicts=slice_conflicts, verbose=0, conflict_budget=budget, **kw)
+    s = Mi355Sat(workers=workers, slice_conflicts=slice_conflicts, verbose=int(os.environ.get('VERBOSE', '0')), conflict_budget=budget, **kw)
     s.add_cnf(cnf.lits, cnf.offsets)
     t = time.time(); r = s.solve(); dt = time.time() - t
     st = s.stats()
@@ -42,6 +42,10 @@ if __name__ == "__main__":
             print(kw, flush=True)
             run("rect24x24", "default", 8, 256, cpu=False, **kw)
             run("rect64x64", "default", 46, 1280, slice_conflicts=100, cpu=False, budget=1280 * 100, **kw)
+    if "w" in which:   # wall-clock to verdict: cube splitting (default) vs plain portfolio
+        for name, pset, k in [("rect24x24", "default", 8), ("rect24x24", "default", 9), ("rect16x16", "1x1", 14), ("rect32x32", "default", 12), ("rect32x32", "default", 13)]:
+            run(name, pset, k, 3072, slice_conflicts=0, cpu=False)
+        run("rect24x24", "default", 8, 3072, slice_conflicts=0, cpu=False, cube_split=-1)
     if "c" in which:
         for W in (256, 1024, 2048, 4096):
             run("rect64x64", "default", 46, W, slice_conflicts=100, cpu=False, budget=W * 100)

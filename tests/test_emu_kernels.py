@@ -118,3 +118,24 @@ def test_interrupt_from_another_thread_and_conflict_budget():
     s.add_cnf(cnf.lits, cnf.offsets)
     assert s.solve() == SolverResult.Interrupted
     s.close()
+
+
+def test_emulated_cube_splitting_partitions_the_search_space():
+    """Work stealing between short slices: an UNSAT verdict needs every split-off cube closed
+    (closed = splits + 1), a SAT model found inside a cube is a model of the whole formula."""
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    for k, want in [(3, SolverResult.Unsat), (4, SolverResult.Sat)]:
+        cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+        s = emu_solver(workers=8, slice_conflicts=8)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        assert s.solve() == want
+        if want == SolverResult.Sat:
+            check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+        s.close()
+    # portfolio mode (no splitting) still answers
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 3}))
+    s = emu_solver(workers=3, slice_conflicts=40, cube_split=-1)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    assert s.solve() == SolverResult.Unsat
+    s.close()

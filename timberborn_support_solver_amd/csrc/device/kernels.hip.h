@@ -1133,7 +1133,7 @@ DEV_COLD void on_fixpoint(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         int a = uni(assumps[w.n_levels]);
         int va = lit_value<LV>(w, sh, L, a);
         if (va == MS_VAL_TRUE) new_decision_level(w, sh, L);      // dummy level
-        else if (va == MS_VAL_FALSE) { w.status = MS_ST_UNSAT; return; }
+        else if (va == MS_VAL_FALSE) { w.status = MS_ST_REFUTED; return; }   // the cube is refuted
         else { next = a; break; }
     }
     if (next < 0) {
@@ -1182,6 +1182,12 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     MsLayout lc = L;
     uint32_t slice_confl = 0;
     const bool entered_running = w.status == MS_ST_RUNNING;
+    if (entered_running && st->restart_req) {   // a new cube was assigned: drop the old search path
+        Wk t = w;
+        cancel_until<LV>(t, sc, lc, 0);
+        w = t;
+        if (w.lane == 0) st->restart_req = 0;
+    }
     const u64 tick0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
     while (w.status == MS_ST_RUNNING) {
         if (prm.slice_ticks && __builtin_amdgcn_s_memrealtime() - tick0 >= prm.slice_ticks) break;
@@ -1203,10 +1209,20 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
             w = t;
         }
     }
-    if (entered_running && w.status != MS_ST_RUNNING && w.lane == 0 && prm.any_done) atomicExch(prm.any_done, 1);
+    if (entered_running && w.lane == 0 && prm.any_done &&
+        (w.status == MS_ST_SAT || w.status == MS_ST_UNSAT || (w.status == MS_ST_REFUTED && prm.done_on_refuted)))
+        atomicExch(prm.any_done, 1);
     lds_fence();
     if (w.lane < MS_LBDQ) st->lbdq[w.lane] = s_lbdq[w.lane];
     if (w.lane == 0) {
+        // offer the oldest free decisions for cube splitting (host-side work stealing)
+        int ns = 0;
+        if (w.status == MS_ST_RUNNING) {
+            const int32_t* tl = WK_PTR(int32_t, w, L, trail_lim);
+            const int32_t* tr = WKA(int32_t, trail);
+            for (int lv = ls.n_assumps; lv < w.n_levels && ns < MS_SPLIT_MAX; lv++) st->split[ns++] = tr[tl[lv]];
+        }
+        st->n_split = ns;
         st->conflicts = ls.conflicts; st->restarts = ls.restarts; st->reduce_dbs = ls.reduce_dbs;
         st->lbdq_sum = ls.lbdq_sum; st->lbd_total = ls.lbd_total; st->next_reduce = ls.next_reduce;
         st->lbdq_n = ls.lbdq_n; st->lbdq_i = ls.lbdq_i; st->trail_avg = ls.trail_avg;

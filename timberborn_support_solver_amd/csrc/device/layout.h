@@ -23,6 +23,7 @@
 #define MS_OVERFLOW_CAP 192       // watcher pushes that found their list full, per chunk
 #define MS_LBDQ 50                // Glucose restart window
 #define MS_MAX_GROUPS 8           // queue literals propagated per step (lane groups per wave)
+#define MS_SPLIT_MAX 8            // decisions a worker offers per slice for splitting its cube
 
 // lit_value() results
 #define MS_VAL_TRUE 0
@@ -49,7 +50,8 @@
 enum {
     MS_ST_RUNNING = 0,
     MS_ST_SAT = 10,
-    MS_ST_UNSAT = 20,          // formula (with this worker's assumptions) refuted
+    MS_ST_UNSAT = 20,          // the formula itself is refuted (conflict without any decision)
+    MS_ST_REFUTED = 21,        // this worker's cube (assumption list) is refuted
     MS_ST_PARKED = 120,        // another worker already decided this instance
     MS_ST_ERR_POOL = -1,       // watch pool exhausted
     MS_ST_ERR_LEARNT = -2,     // learnt clause store exhausted
@@ -111,7 +113,9 @@ struct MsState {
     int32_t trail_n, qhead, n_levels;
     int32_t n_assumps;
     int32_t n_script;
-    int32_t pad0[2];
+    int32_t restart_req;       // host assigned a new cube: backtrack to level 0 before continuing
+    int32_t n_split;           // split[0..n_split): this worker's decisions right above its cube, oldest first
+    int32_t split[MS_SPLIT_MAX];
     // decision queue
     int32_t vm_end, vm_search;
     // learnt store
@@ -145,5 +149,7 @@ struct MsParams {
     int32_t stop_on_any;           // leave when any worker has finished (any_done)
     int32_t max_groups;            // 1..MS_MAX_GROUPS queue literals per BCP step
     int32_t* any_done;             // device int, set when a worker reaches SAT/UNSAT
+    int32_t done_on_refuted;       // a refuted cube also raises any_done (portfolio mode: it decides the instance)
+    int32_t pad;
     uint32_t reduce_first, reduce_inc;
 };

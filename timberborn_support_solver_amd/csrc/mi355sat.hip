@@ -46,7 +46,7 @@ struct HipErr { std::string msg; };
 // (affine permutation of the variables; worker group 0 keeps the canonical order).
 __global__ void ms_customize_kernel(MsLayout L, char* slabs, uint32_t n_workers, const int32_t* assump_data,
                                     const uint64_t* assump_off, const int32_t* script_data,
-                                    const uint64_t* script_off, uint32_t n_instances, uint64_t seed) {
+                                    const uint64_t* script_off, uint32_t n_instances, uint64_t seed, int32_t park_from) {
     const uint32_t wid = blockIdx.x;
     if (wid >= n_workers) return;
     char* slab = slabs + (size_t)wid * L.slab_bytes;
@@ -65,7 +65,10 @@ __global__ void ms_customize_kernel(MsLayout L, char* slabs, uint32_t n_workers,
         for (uint64_t i = threadIdx.x; i < a1 - a0; i += blockDim.x) dst[i] = script_data[a0 + i];
         if (threadIdx.x == 0) st->n_script = (int32_t)(a1 - a0);
     }
-    if (threadIdx.x == 0) st->rng = seed * 0x9E3779B97F4A7C15ull + wid;
+    if (threadIdx.x == 0) {
+        st->rng = seed * 0x9E3779B97F4A7C15ull + wid;
+        if (park_from >= 0 && (int32_t)wid >= park_from) st->status = MS_ST_PARKED;  // idle until it steals a cube
+    }
     if (replica > 0 && L.n_vars > 2) {
         // splitmix64 -> multiplier coprime to n_vars, offset
         uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(replica + 1);
@@ -101,6 +104,25 @@ __global__ void ms_replicate_kernel(const char* tmpl, char* slabs, uint64_t slab
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_head + n_pool; i += stride) {
         const uint64_t off = i < n_head ? i * 16 : pool_off + (i - n_head) * 16;
         *(uint4*)(dst + off) = *(const uint4*)(tmpl + off);
+    }
+}
+
+// Applies the scheduler's decisions between two slices: update u = (worker, status, restart_req,
+// n_assumps, data offset); the worker's assumption list (its cube) is rewritten from data[].
+__global__ void ms_assign_kernel(MsLayout L, char* slabs, uint32_t n_upd, const int32_t* upd, const int32_t* data) {
+    const uint32_t u = blockIdx.x;
+    if (u >= n_upd) return;
+    const int32_t worker = upd[5 * u], status = upd[5 * u + 1], restart = upd[5 * u + 2], n = upd[5 * u + 3],
+                  off = upd[5 * u + 4];
+    char* slab = slabs + (size_t)worker * L.slab_bytes;
+    MsState* st = (MsState*)(slab + L.state);
+    int32_t* dst = (int32_t*)(slab + L.assumps);
+    for (int32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = data[off + i];
+    if (threadIdx.x == 0) {
+        st->n_assumps = n;
+        st->status = status;
+        if (restart) st->restart_req = 1;
+        st->n_split = 0;
     }
 }
 
@@ -479,7 +501,8 @@ void reset_workers(mi355sat& s) {
 }
 
 void customize(mi355sat& s, const std::vector<int32_t>* assump, const std::vector<uint64_t>* assump_off,
-               const std::vector<int32_t>* script, const std::vector<uint64_t>* script_off, uint32_t n_instances) {
+               const std::vector<int32_t>* script, const std::vector<uint64_t>* script_off, uint32_t n_instances,
+               int32_t park_from = -1) {
     if (assump_off) {
         s.d_assump.upload(assump->empty() ? std::vector<int32_t>{0} : *assump, s.stream);
         s.d_assump_off.upload(*assump_off, s.stream);
@@ -491,7 +514,7 @@ void customize(mi355sat& s, const std::vector<int32_t>* assump, const std::vecto
     hipLaunchKernelGGL(ms_customize_kernel, dim3(s.n_workers), dim3(256), 0, s.stream, s.L, s.d_slabs.p,
                        s.n_workers, assump_off ? s.d_assump.p : nullptr, assump_off ? s.d_assump_off.p : nullptr,
                        script_off ? s.d_script.p : nullptr, script_off ? s.d_script_off.p : nullptr, n_instances,
-                       s.opts.seed);
+                       s.opts.seed, park_from);
     HIPCHK(hipGetLastError());
 }
 
@@ -541,7 +564,7 @@ void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_
 
 struct SliceResult { float ms; };
 
-SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any) {
+SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_refuted = true) {
     MsParams prm{};
     prm.n_workers = s.n_workers;
     prm.slice_conflicts = s.opts.slice_conflicts > 0 ? (uint32_t)s.opts.slice_conflicts : 0xffffffffu;
@@ -553,6 +576,7 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any) {
     prm.stop_on_any = stop_on_any ? 1 : 0;
     prm.max_groups = s.opts.max_groups > 0 ? s.opts.max_groups : MS_MAX_GROUPS;
     prm.any_done = s.d_any_done.p;
+    prm.done_on_refuted = done_on_refuted ? 1 : 0;
     prm.reduce_first = s.opts.reduce_first > 0 ? (uint32_t)s.opts.reduce_first : 2000u;
     prm.reduce_inc = s.opts.reduce_inc > 0 ? (uint32_t)s.opts.reduce_inc : 300u;
     const uint32_t dyn = s.lds_val ? s.lds_val_bytes : 0;
@@ -593,15 +617,26 @@ struct Sweep {
     bool active = false;
     std::vector<MsState> sts;
     uint64_t conflicts = 0;
+    // cube scheduler (opts.cube_split): every busy worker owns one cube = its instance's base
+    // assumptions + split literals; the cubes of an instance partition its search space
+    bool split = false;
+    std::vector<int32_t> w_inst;
+    std::vector<std::vector<int32_t>> w_cube;   // internal literals
+    std::vector<uint8_t> w_busy;
+    std::vector<uint64_t> w_conf0;               // worker's conflict count when it got its cube
+    std::vector<uint32_t> open;                  // open cubes per instance
+    uint64_t n_splits = 0, n_closed = 0;
+    DevBuf<int32_t> d_upd, d_data;
 };
 
 int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, const std::vector<uint64_t>& assump_off,
                 uint32_t n_instances, bool stop_at_first) {
     Prepared P;
     prepare(s, /*simplify=*/true, P);
-    sw = Sweep{};
     sw.n_instances = n_instances;
     sw.stop_at_first = stop_at_first;
+    sw.decided = 0;
+    sw.active = false;
     sw.results.assign(n_instances, MI355SAT_INTERRUPTED);
     sw.winner.assign(n_instances, -1);
     if (P.unsat) {
@@ -610,64 +645,151 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
         s.trivially_unsat = true;
         return 0;
     }
-    uint32_t max_assumps = 0;
-    for (uint32_t i = 0; i < n_instances; i++)
-        max_assumps = std::max<uint32_t>(max_assumps, (uint32_t)(assump_off[i + 1] - assump_off[i]));
-    // default worker count: the resident capacity (12 wavefronts on each of 256 CUs) for large formulas,
-    // one wavefront per CU for small ones (their slabs are replicated per solve; keep that cheap)
     uint32_t want = s.opts.workers > 0 ? (uint32_t)s.opts.workers : (s.offs.size() > 100000 ? 3072u : 256u);
     if (want < n_instances) want = n_instances;
     want = want / n_instances * n_instances;
+    sw.split = s.opts.cube_split >= 0 && want > n_instances;
     std::vector<int32_t> a_int(assump.size());
     for (size_t i = 0; i < assump.size(); i++) {
         int32_t d = assump[i];
         if (d == 0 || (uint64_t)(d < 0 ? -(int64_t)d : d) > P.n_vars) throw HipErr{"assumption literal out of range"};
         a_int[i] = to_internal(d);
     }
-    upload_formula(s, P, max_assumps, 0, want);
+    uint32_t max_assumps = 0;
+    for (uint32_t i = 0; i < n_instances; i++)
+        max_assumps = std::max<uint32_t>(max_assumps, (uint32_t)(assump_off[i + 1] - assump_off[i]));
+    const uint32_t assump_cap = sw.split ? max_assumps + 512 : max_assumps;
+    upload_formula(s, P, assump_cap, 0, want);
     if (s.n_workers < n_instances) throw HipErr{"not enough device memory for one worker per instance"};
     s.n_workers = s.n_workers / n_instances * n_instances;
     reset_workers(s);
-    customize(s, &a_int, &assump_off, nullptr, nullptr, n_instances);
+    customize(s, &a_int, &assump_off, nullptr, nullptr, n_instances, sw.split ? (int32_t)n_instances : -1);
     HIPCHK(hipStreamSynchronize(s.stream));
+    const uint32_t W = s.n_workers;
+    sw.w_inst.assign(W, 0);
+    sw.w_cube.assign(W, {});
+    sw.w_busy.assign(W, 0);
+    sw.w_conf0.assign(W, 0);
+    sw.open.assign(n_instances, 0);
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t inst = w % n_instances;
+        sw.w_inst[w] = (int32_t)inst;
+        if (!sw.split || w < n_instances) {
+            sw.w_busy[w] = 1;
+            sw.w_cube[w].assign(a_int.begin() + assump_off[inst], a_int.begin() + assump_off[inst + 1]);
+            sw.open[inst]++;
+        }
+    }
     sw.active = true;
     return 0;
+}
+
+// Work stealing between two slices: idle workers take over sub-cubes split off the oldest free
+// decisions of running workers.  Victim with cube C and decisions d1..dm keeps C,d1..dm; thief j
+// gets C,d1..d(j-1),~dj — together they partition C, so an instance is UNSAT exactly when all its
+// cubes are closed.
+void schedule_cubes(mi355sat& s, Sweep& sw) {
+    const uint32_t W = s.n_workers, cap = s.L.assump_cap;
+    std::vector<int32_t> upd, data;
+    auto push_update = [&](uint32_t w, int32_t status, int32_t restart) {
+        upd.insert(upd.end(), {(int32_t)w, status, restart, (int32_t)sw.w_cube[w].size(), (int32_t)data.size()});
+        data.insert(data.end(), sw.w_cube[w].begin(), sw.w_cube[w].end());
+    };
+    std::vector<uint32_t> idle, victims;
+    for (uint32_t w = 0; w < W; w++) {
+        const bool undecided = sw.results[sw.w_inst[w]] == MI355SAT_INTERRUPTED;
+        if (sw.w_busy[w] && !undecided) {   // its instance was decided by someone else: park it
+            sw.w_busy[w] = 0;
+            if (sw.sts[w].status == MS_ST_RUNNING) { sw.w_cube[w].clear(); push_update(w, MS_ST_PARKED, 0); sw.sts[w].status = MS_ST_PARKED; }
+        }
+        if (!sw.w_busy[w]) idle.push_back(w);
+        else if (sw.sts[w].status == MS_ST_RUNNING && sw.sts[w].n_split > 0) victims.push_back(w);
+    }
+    // hardest cubes first: most conflicts spent on the current cube
+    std::sort(victims.begin(), victims.end(), [&](uint32_t a, uint32_t b) {
+        return sw.sts[a].conflicts - sw.w_conf0[a] > sw.sts[b].conflicts - sw.w_conf0[b];
+    });
+    std::vector<uint32_t> taken(W, 0);
+    size_t next_idle = 0;
+    for (uint32_t round = 0; round < MS_SPLIT_MAX && next_idle < idle.size(); round++) {
+        bool any = false;
+        for (uint32_t v : victims) {
+            if (next_idle >= idle.size()) break;
+            if (taken[v] != round || (int32_t)round >= sw.sts[v].n_split) continue;
+            if (sw.w_cube[v].size() + 1 > cap) continue;
+            const int32_t d = sw.sts[v].split[round];
+            const uint32_t t = idle[next_idle++];
+            sw.w_cube[t] = sw.w_cube[v];
+            sw.w_cube[t].push_back(d ^ 1);
+            sw.w_cube[v].push_back(d);
+            sw.w_inst[t] = sw.w_inst[v];
+            sw.w_busy[t] = 1;
+            sw.w_conf0[t] = sw.sts[t].conflicts;
+            sw.open[sw.w_inst[v]]++;
+            sw.n_splits++;
+            taken[v] = round + 1;
+            push_update(t, MS_ST_RUNNING, 1);
+            any = true;
+        }
+        if (!any) break;
+    }
+    for (uint32_t v : victims)
+        if (taken[v]) push_update(v, MS_ST_RUNNING, 0);
+    if (upd.empty()) return;
+    sw.d_upd.upload(upd, s.stream);
+    sw.d_data.upload(data.empty() ? std::vector<int32_t>{0} : data, s.stream);
+    hipLaunchKernelGGL(ms_assign_kernel, dim3((uint32_t)(upd.size() / 5)), dim3(64), 0, s.stream, s.L, s.d_slabs.p,
+                       (uint32_t)(upd.size() / 5), sw.d_upd.p, sw.d_data.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s.stream));
 }
 
 // One slice of the search kernel over all workers.  Returns 0 or a negative error.
 int sweep_step(mi355sat& s, Sweep& sw) {
     if (!sw.active) return 0;
     const uint32_t n_instances = sw.n_instances;
-    launch_slice(s, 0, /*stop_on_any=*/n_instances == 1 || sw.stop_at_first);
+    launch_slice(s, 0, /*stop_on_any=*/n_instances == 1 || sw.stop_at_first, /*done_on_refuted=*/!sw.split);
     gather_states(s, sw.sts);
     int rc = 0;
     uint64_t confl = 0;
     for (uint32_t w = 0; w < s.n_workers; w++) {
         const MsState& st = sw.sts[w];
         confl += st.conflicts;
-        uint32_t inst = w % n_instances;
         if (st.status < 0) {
             set_error(&s, status_text(st.status));
             rc = st.status == MS_ST_ERR_INTERNAL ? MI355SAT_ERR_STATE : MI355SAT_ERR_OOM;
         }
+        if (!sw.w_busy[w]) continue;
+        const uint32_t inst = (uint32_t)sw.w_inst[w];
+        if (st.status == MS_ST_REFUTED || st.status == MS_ST_UNSAT) {   // this worker's cube is closed
+            sw.w_busy[w] = 0;
+            sw.open[inst]--;
+            sw.n_closed++;
+        }
         if (sw.results[inst] != MI355SAT_INTERRUPTED) continue;
         if (st.status == MS_ST_SAT) { sw.results[inst] = MI355SAT_SAT; sw.winner[inst] = (int32_t)w; sw.decided++; }
-        else if (st.status == MS_ST_UNSAT) { sw.results[inst] = MI355SAT_UNSAT; sw.winner[inst] = (int32_t)w; sw.decided++; }
+        else if (st.status == MS_ST_UNSAT || (st.status == MS_ST_REFUTED && (!sw.split || sw.open[inst] == 0))) {
+            // the formula itself refuted, or (with splitting) the last open cube of the instance closed;
+            // without splitting every worker holds the instance's whole search space
+            sw.results[inst] = MI355SAT_UNSAT; sw.winner[inst] = (int32_t)w; sw.decided++;
+        }
     }
     sw.conflicts = confl;
     if (s.opts.verbose) {
-        uint64_t props = 0;
-        for (auto& st : sw.sts) props += st.propagations;
-        uint64_t nl = 0, ll = 0, lt = 0, llt = 0;
-        for (auto& st : sw.sts) { nl += st.n_learnts; ll += st.lc_lits_n; lt += st.learnt_total; llt += st.learnt_lits_total; }
-        fprintf(stderr, "[mi355sat] slice: decided %u/%u conflicts=%llu props=%llu kernel=%.3fs kept=%llu (avg len %.1f) learnt avg len %.1f\n",
+        uint64_t props = 0, nl = 0, ll = 0, busy = 0;
+        for (auto& st : sw.sts) { props += st.propagations; nl += st.n_learnts; ll += st.lc_lits_n; }
+        for (auto b : sw.w_busy) busy += b;
+        fprintf(stderr, "[mi355sat] slice: decided %u/%u conflicts=%llu props=%llu kernel=%.3fs busy=%llu/%u splits=%llu closed=%llu kept=%llu\n",
                 sw.decided, n_instances, (unsigned long long)confl, (unsigned long long)props, s.stats.kernel_seconds,
-                (unsigned long long)nl, nl ? (double)ll / nl : 0.0, lt ? (double)llt / lt : 0.0);
+                (unsigned long long)busy, s.n_workers, (unsigned long long)sw.n_splits, (unsigned long long)sw.n_closed,
+                (unsigned long long)nl);
     }
     if (rc) return rc;
-    // clear the stop-on-any latch and park the still-running workers of decided instances
     HIPCHK(hipMemsetAsync(s.d_any_done.p, 0, sizeof(int32_t), s.stream));
-    if (n_instances > 1 && sw.decided > 0 && sw.decided < n_instances) {
+    if (sw.decided == n_instances || (sw.stop_at_first && sw.decided > 0)) return 0;
+    if (sw.split) schedule_cubes(s, sw);
+    else if (n_instances > 1 && sw.decided > 0) {
+        // portfolio mode: park the still-running workers of decided instances
         for (uint32_t w = 0; w < s.n_workers; w++) {
             uint32_t inst = w % n_instances;
             if (sw.results[inst] != MI355SAT_INTERRUPTED && sw.sts[w].status == MS_ST_RUNNING) {
@@ -675,6 +797,7 @@ int sweep_step(mi355sat& s, Sweep& sw) {
                 HIPCHK(hipMemcpyAsync(s.d_slabs.p + (size_t)w * s.L.slab_bytes + s.L.state + offsetof(MsState, status),
                                       &parked, sizeof parked, hipMemcpyHostToDevice, s.stream));
                 sw.sts[w].status = MS_ST_PARKED;
+                sw.w_busy[w] = 0;
             }
         }
         HIPCHK(hipStreamSynchronize(s.stream));
