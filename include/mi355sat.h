@@ -69,8 +69,9 @@ typedef struct mi355sat_opts {
     int32_t lds_val;           /* assignment in LDS (2 bits/var): 0 auto, 1 force, -1 never */
     int32_t max_groups;        /* queue literals propagated per BCP step: 1..8; 0 = 8 */
     int32_t slice_ms;          /* wall-time bound of one kernel launch in ms (all workers stop together); 0 = 20 */
-    int32_t cube_split;        /* 0 (default): idle workers steal sub-cubes of running ones between slices;
-                                  -1: plain portfolio, every worker searches the whole instance */
+    int32_t cube_split;        /* 0 (default): portfolio, every worker of an instance searches the whole instance with its
+                                  own decision order; 1: idle workers steal sub-cubes of running ones between slices
+                                  (correct but, as measured in round 1, slower: DESIGN.md) */
     int32_t reserved[2];
 } mi355sat_opts;
 

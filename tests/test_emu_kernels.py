@@ -127,7 +127,7 @@ def test_emulated_cube_splitting_partitions_the_search_space():
     enc = Encoding.encode(platform_defs("1x1"), grid)
     for k, want in [(3, SolverResult.Unsat), (4, SolverResult.Sat)]:
         cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
-        s = emu_solver(workers=8, slice_conflicts=8)
+        s = emu_solver(workers=8, slice_conflicts=8, cube_split=1)
         s.add_cnf(cnf.lits, cnf.offsets)
         assert s.solve() == want
         if want == SolverResult.Sat:
@@ -135,7 +135,7 @@ def test_emulated_cube_splitting_partitions_the_search_space():
         s.close()
     # portfolio mode (no splitting) still answers
     cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 3}))
-    s = emu_solver(workers=3, slice_conflicts=40, cube_split=-1)
+    s = emu_solver(workers=3, slice_conflicts=40)
     s.add_cnf(cnf.lits, cnf.offsets)
     assert s.solve() == SolverResult.Unsat
     s.close()

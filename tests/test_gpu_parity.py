@@ -138,6 +138,20 @@ def test_full_size_64x64_properties():
     s.close()
 
 
+def test_cube_splitting_mode_gives_the_same_verdicts():
+    """Opt-in work stealing: the cubes partition the search space, so verdicts must not change."""
+    grid = make_grid("rect16x16")
+    enc = Encoding.encode(platform_defs("default"), grid)
+    for k, want in [(3, SolverResult.Unsat), (4, SolverResult.Sat)]:
+        cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+        s = Mi355Sat(workers=256, cube_split=1, slice_ms=2)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        assert s.solve() == want
+        if want == SolverResult.Sat:
+            check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+        s.close()
+
+
 def test_interrupt_and_budget():
     grid = make_grid("rect16x16")
     enc = Encoding.encode(platform_defs("1x1"), grid)
