@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--k-hi", type=int, default=51)
     ap.add_argument("--workers", type=int, default=3072, help="wavefront workers per GPU (12 per CU)")
     ap.add_argument("--slice-ms", type=int, default=250, help="device time of one step (one kernel launch)")
-    ap.add_argument("--cpu-conflicts", type=int, default=20000, help="conflict budget of the CPU baseline sample")
+    ap.add_argument("--cpu-conflicts", type=int, default=200000, help="conflict budget of the CPU baseline sample (~10-15 s)")
+    ap.add_argument("--first-unsat-size", type=int, default=24, help="rect size of the wall-clock-to-first-UNSAT rung (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--platforms", default="default", choices=["default", "1x1"])
     args = ap.parse_args()
@@ -135,6 +136,56 @@ def main():
 
     solver.sweep_end()
     solver.close()
+
+    # ---- wall-clock to first UNSAT on the largest rung that finishes in bench time (64x64 does not:
+    # SURVEY §6).  GPU: the whole sweep k_hi..0 as one batch over one CNF until the cut closes
+    # (max UNSAT k + 1 == min SAT k).  CPU: the reference's sequential loop (k := count - 1) on the oracle.
+    first_unsat = None
+    if rank == 0 and world == 1 and args.first_unsat_size > 0 and not args.no_cpu:
+        from oracle import oracle as ora
+        from timberborn_support_solver_amd import PlatformLayout
+        m = args.first_unsat_size
+        g2 = WorldGrid.rect(m, m)
+        e2 = Encoding.encode(defs, g2)
+        k0 = max(4, m * m // 24)
+        c2 = e2.with_limits_into_cnf(PlatformLimits({(1, 1): k0}), sweep=True)
+        ks2 = list(range(k0, -1, -1))
+        sets2 = [([-int(c2.card_outputs[k])] if k < k0 else []) for k in ks2]
+        sv = Mi355Sat(device=local_rank, workers=max(len(ks2), 3072 // len(ks2) * len(ks2)), slice_ms=10)
+        sv.add_cnf(c2.lits, c2.offsets)
+        tg = time.perf_counter()
+        sv.sweep_begin(sets2)
+        kstar = None
+        while time.perf_counter() - tg < 120:
+            res2, _ = sv.sweep_step()
+            sat_k = min([k for k, r in zip(ks2, res2) if r == SolverResult.Sat], default=None)
+            unsat_k = max([k for k, r in zip(ks2, res2) if r == SolverResult.Unsat], default=None)
+            if sat_k is not None and unsat_k is not None and unsat_k + 1 >= sat_k:
+                kstar = sat_k
+                break
+        gpu_s = time.perf_counter() - tg
+        sv.sweep_end()
+        sv.close()
+        # CPU: decreasing-k loop, fresh solver per k (crates/repl/src/main.rs:290-346)
+        tc = time.perf_counter()
+        k, cpu_kstar = k0, None
+        while time.perf_counter() - tc < 120:
+            ck = e2.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+            o = ora.OracleSolver()
+            o.add_cnf(ck.lits, ck.offsets)
+            r = o.solve(conflict_budget=5_000_000)
+            if r == 20:
+                cpu_kstar = k + 1
+                break
+            if r != 10:
+                break
+            cnt = PlatformLayout.from_assignment(o.model(ck.n_vars)[:e2.n_vars], e2).platform_count()
+            k = cnt - 1
+        cpu_s = time.perf_counter() - tc
+        first_unsat = {"instance": f"rect {m} {m} {args.platforms}, sweep from k={k0}", "optimum_k": kstar,
+                       "gpu_seconds": gpu_s if kstar is not None else None, "cpu_seconds": cpu_s if cpu_kstar is not None else None,
+                       "cpu_optimum_k": cpu_kstar, "cpu_kind": "port (oracle CDCL restatement, 1 core)",
+                       "note": "rect 64 64 to a proven first UNSAT is out of reach for both sides (area bound k* >= 43)"}
     if rank == 0:
         kern_s = d["kernel_seconds"]
         launches = max(1, d["kernel_launches"])
@@ -159,7 +210,8 @@ def main():
                        "parallelism": f"{world} GPU(s) x {workers} wavefront workers, seeds sharded over ranks"},
             "conflicts_per_s": total_confl / max_dt,
             "decided_instances": int(decided),
-            "first_unsat_wall_clock_s": None,
+            "first_unsat_wall_clock_s": first_unsat["gpu_seconds"] if first_unsat else None,
+            "first_unsat": first_unsat,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "ms_search_kernel", "kernel_ms_avg": kern_s / launches * 1e3,

@@ -45,7 +45,7 @@ def test_product_sources_never_touch_the_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                 src = open(os.path.join(d, f), errors="ignore").read()
-                assert "oracle" not in src.lower() or f == "solver.py" and False, os.path.join(d, f)
+                assert "oracle" not in src.lower(), os.path.join(d, f)
 
 
 def test_signature_and_opts_struct_layout():

@@ -1,0 +1,61 @@
+// tbs_cli — minimal command-line driver of the solve path (NOT the reference's REPL/UI):
+//   tbs_cli rect W H [-l1:K] [--platforms default|1x1] [--workers N]
+//   tbs_cli file PATH.toml [-l1:K] ...
+// Mirrors `solve -l<dims>:<n>` of crates/repl/src/main.rs:44-75,248-261: encode once, then solver_loop.
+// Ctrl-C calls mi355sat_interrupt (main.rs:297-324).
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "solver_loop.hpp"
+
+static std::atomic<mi355sat*> g_current{nullptr};
+static void on_sigint(int) {
+    mi355sat* s = g_current.load();
+    if (s) mi355sat_interrupt(s);
+}
+
+int main(int argc, char** argv) {
+    using namespace tbs;
+    try {
+        if (argc < 3) {
+            fprintf(stderr, "usage: %s rect W H | file PATH [-l<dims>:<n>]... [--platforms default|1x1] [--workers N]\n", argv[0]);
+            return 2;
+        }
+        WorldGrid grid;
+        int a = 1;
+        if (!strcmp(argv[a], "rect") && argc >= 4) { grid = WorldGrid::rect(atoi(argv[a + 1]), atoi(argv[a + 2])); a += 3; }
+        else if (!strcmp(argv[a], "file")) { grid = WorldGrid::from_toml_file(argv[a + 1]); a += 2; }
+        else throw std::runtime_error("expected `rect W H` or `file PATH`");
+        std::vector<Dims> defs = platforms_default();
+        PlatformLimits limits;
+        mi355sat_opts opts{};
+        opts.device = -1;
+        for (; a < argc; a++) {
+            std::string arg = argv[a];
+            if (arg.rfind("-l", 0) == 0) {             // -l<dims>:<n>, dims = AxB or A (=AxA), main.rs:120-142
+                std::string kv = arg.substr(2);
+                size_t c = kv.find(':');
+                if (c == std::string::npos) throw std::runtime_error("missing/invalid delimiter");
+                std::string d = kv.substr(0, c);
+                size_t x = d.find('x');
+                Dims dims = x == std::string::npos ? Dims{atoi(d.c_str()), atoi(d.c_str())}
+                                                   : Dims{atoi(d.substr(0, x).c_str()), atoi(d.substr(x + 1).c_str())};
+                limits.card_limits[dims] = (size_t)atol(kv.substr(c + 1).c_str());
+            } else if (arg == "--platforms" && a + 1 < argc) {
+                if (!strcmp(argv[++a], "1x1")) defs = {Dims{1, 1}};
+            } else if (arg == "--workers" && a + 1 < argc) opts.workers = atoi(argv[++a]);
+            else throw std::runtime_error("unknown argument " + arg);
+        }
+        Encoding enc = Encoding::encode(defs, grid);
+        signal(SIGINT, on_sigint);
+        auto hist = solver_loop(grid, enc, limits, &opts, [](const std::string& l) { std::cout << l << std::endl; },
+                                [](mi355sat* s) { g_current.store(s); });
+        return hist.empty() ? 1 : 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "Error: %s\n", e.what());
+        return 1;
+    }
+}
