@@ -101,6 +101,13 @@ template <class T>
 static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T>
 static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T>
+static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T>
+static inline T __hip_atomic_fetch_or(T* p, T v, int, int) { T o = *p; *p = o | v; return o; }
+template <class T>
+static inline T __hip_atomic_fetch_and(T* p, T v, int, int) { T o = *p; *p = o & v; return o; }
 // dynamic LDS: one static 160 KiB block per (sequentially executed) workgroup
 #define HIP_DYNAMIC_SHARED(type, var) static type var[163840 / sizeof(type)];
 

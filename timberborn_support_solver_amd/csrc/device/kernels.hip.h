@@ -93,6 +93,7 @@ struct Wk {
 // pointers held per worker: `sh` = shared immutable CSRs, `L` = offsets inside the private slab.
 #define WK_PTR(T, w, L, field) ((T*)((w).slab + (L).field))
 #define WKA(T, field) ((T*)(w.slab + L.field))
+#define VREC WKA(MsVarRec, vrec)
 
 DEV u64 ballot(bool p) { return __ballot(p); }
 DEV int popc64(u64 m) { return __popcll(m); }
@@ -118,24 +119,31 @@ DEV u64 wave_sum_u32(uint32_t v) {
 }
 
 // ---- assignment ------------------------------------------------------------------
+// 2 bits per variable (bit1 assigned, bit0 sign), 16 variables per word.  LV: the words are staged in
+// LDS for the slice.  Otherwise they stay in HBM and are read / updated at L2 (agent-scope relaxed
+// atomics: loads bypass the per-CU L1, updates are fire-and-forget OR / AND), so lanes see each other's
+// assignments without any fence.
 template <bool LV>
 DEV int lit_value(const Wk& w, const MsShared& sh, const MsLayout& L, int lit) {  // MS_VAL_TRUE / FALSE / UNDEF
     const int v = lit >> 1;
     uint32_t x;
-    if (LV) x = (w.lval[v >> 4] >> ((v & 15) * 2)) & 3u;
-    else x = WKA(uint8_t, val)[v];
+    if (LV) x = w.lval[v >> 4];
+    else x = __hip_atomic_load(WKA(uint32_t, val) + (v >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x = (x >> ((v & 15) * 2)) & 3u;
     return (x & 2u) ? (int)((x ^ (uint32_t)lit) & 1u) : MS_VAL_UNDEF;
 }
 template <bool LV>
 DEV void asg_set(Wk& w, const MsShared& sh, const MsLayout& L, int lit) {  // variable currently unassigned
     const int v = lit >> 1;
-    if (LV) atomicOr((uint32_t*)&w.lval[v >> 4], (2u | (uint32_t)(lit & 1)) << ((v & 15) * 2));
-    else WKA(uint8_t, val)[v] = (uint8_t)(2 | (lit & 1));
+    const uint32_t bits = (2u | (uint32_t)(lit & 1)) << ((v & 15) * 2);
+    if (LV) atomicOr((uint32_t*)&w.lval[v >> 4], bits);
+    else __hip_atomic_fetch_or(WKA(uint32_t, val) + (v >> 4), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool LV>
 DEV void asg_clear(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
-    if (LV) atomicAnd((uint32_t*)&w.lval[v >> 4], ~(3u << ((v & 15) * 2)));
-    else WKA(uint8_t, val)[v] = MS_ASG_UNDEF;
+    const uint32_t mask = ~(3u << ((v & 15) * 2));
+    if (LV) atomicAnd((uint32_t*)&w.lval[v >> 4], mask);
+    else __hip_atomic_fetch_and(WKA(uint32_t, val) + (v >> 4), mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 DEV void clause_range(const Wk& w, const MsShared& sh, const MsLayout& L, int c, const int32_t*& lits, int& size) {
@@ -162,8 +170,8 @@ DEV void enqueue_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int lit, 
     if (w.lane == 0) {
         int v = lit >> 1;
         asg_set<LV>(w, sh, L, lit);
-        WKA(int32_t, level)[v] = w.n_levels;
-        WKA(int32_t, reason)[v] = reason;
+        VREC[v].level = w.n_levels;
+        VREC[v].reason = reason;
         WKA(int32_t, trail)[w.trail_n] = lit;
         w.ring[w.trail_n & (MS_LDS_RING - 1)] = lit;
     }
@@ -185,8 +193,8 @@ DEV void commit_implications(Wk& w, const MsShared& sh, const MsLayout& L, bool 
         if (want) {
             int v = q >> 1;
             asg_set<LV>(w, sh, L, q);
-            WKA(int32_t, level)[v] = w.n_levels;
-            WKA(int32_t, reason)[v] = reason;
+            VREC[v].level = w.n_levels;
+            VREC[v].reason = reason;
             WKA(int32_t, trail)[w.trail_n] = q;
             w.ring[w.trail_n & (MS_LDS_RING - 1)] = q;
         }
@@ -213,8 +221,8 @@ DEV void commit_implications(Wk& w, const MsShared& sh, const MsLayout& L, bool 
             int v = q >> 1;
             int t = w.trail_n + popc64(wm & lanemask_lt(w.lane));
             asg_set<LV>(w, sh, L, q);
-            WKA(int32_t, level)[v] = w.n_levels;
-            WKA(int32_t, reason)[v] = reason;
+            VREC[v].level = w.n_levels;
+            VREC[v].reason = reason;
             WKA(int32_t, trail)[t] = q;
             w.ring[t & (MS_LDS_RING - 1)] = q;
         }
@@ -397,6 +405,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
             const int i = it * S + sl;
             const bool act = i < n;
             int2 wt = it == 0 ? wt0 : (act ? pool[wb + i] : make_int2(-1, 0));
+            const int blocker0 = wt.y;
             const bool live = act && wt.x >= 0;       // cref < 0: tombstone left by an interrupted pass
             bool keep = live, want = false, cf = false, deferred = false;
             // phase A (per lane): blocker, the other watch, the first literals of the clause
@@ -471,7 +480,10 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
             // in-place compaction of the kept watchers of each group's list (dest <= source)
             const u64 km = ballot(keep);
             wave_fence();
-            if (keep) pool[wb + j + popc64(km & gmask & lanemask_lt(w.lane))] = wt;
+            {   // a watcher that stays in place with its old blocker is not written back (saves a dirty line)
+                const int d = j + popc64(km & gmask & lanemask_lt(w.lane));
+                if (keep && (d != i || wt.y != blocker0)) pool[wb + d] = wt;
+            }
             j += popc64(km & gmask);
             done = min(n, (it + 1) * S);
             const u64 dm = ballot(deferred);
@@ -513,15 +525,14 @@ template <bool LV>
 DEV void cancel_until(Wk& w, const MsShared& sh, const MsLayout& L, int lvl) {
     if (w.n_levels <= lvl) return;
     const int lim = uni(WK_PTR(int32_t, w, L, trail_lim)[lvl]);
-    uint8_t* phase = WK_PTR(uint8_t, w, L, phase);
-    const int32_t* vm_pos = WK_PTR(int32_t, w, L, vm_pos);
+    MsVarRec* vrec = VREC;
     int maxpos = -1;
     for (int i = lim + w.lane; i < w.trail_n; i += MS_WAVE) {
         int l = WKA(int32_t, trail)[i];
         int v = l >> 1;
         asg_clear<LV>(w, sh, L, v);
-        phase[v] = (uint8_t)(l & 1);
-        maxpos = max(maxpos, vm_pos[v]);
+        vrec[v].phase = (uint8_t)(l & 1);
+        maxpos = max(maxpos, vrec[v].vm_pos);
     }
     maxpos = wave_max(maxpos);
     if (maxpos > w.vm_search) w.vm_search = maxpos;
@@ -543,19 +554,19 @@ DEV void new_decision_level(Wk& w, const MsShared& sh, const MsLayout& L) {
 // it is assigned.
 DEV void vm_compact(Wk& w, const MsShared& sh, const MsLayout& L) {
     int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
-    int32_t* vm_pos = WK_PTR(int32_t, w, L, vm_pos);
+    MsVarRec* vrec = VREC;
     int j = 0;
     for (int i0 = 0; i0 < w.vm_end; i0 += MS_WAVE) {
         int i = i0 + w.lane;
         int v = -1;
         bool live = false;
-        if (i < w.vm_end) { v = vm_order[i]; live = vm_pos[v] == i; }
+        if (i < w.vm_end) { v = vm_order[i]; live = vrec[v].vm_pos == i; }
         u64 m = ballot(live);
         wave_fence();
         if (live) {
             int d = j + popc64(m & lanemask_lt(w.lane));
             vm_order[d] = v;
-            vm_pos[v] = d;
+            vrec[v].vm_pos = d;
         }
         j += popc64(m);
         wave_fence();
@@ -582,7 +593,7 @@ DEV void vm_compact_call(Wk& w, const MsShared& sh, const MsLayout& L) {
 template <bool LV>
 DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
     const int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
-    const int32_t* vm_pos = WK_PTR(int32_t, w, L, vm_pos);
+    const MsVarRec* vrec = VREC;
     for (;;) {
         if (w.vm_search < 0) return -1;
         int idx = w.vm_search - w.lane;
@@ -590,7 +601,7 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
         bool ok = false;
         if (idx >= 0) {
             v = vm_order[idx];
-            ok = vm_pos[v] == idx && lit_value<LV>(w, sh, L, 2 * v) == MS_VAL_UNDEF;
+            ok = vrec[v].vm_pos == idx && lit_value<LV>(w, sh, L, 2 * v) == MS_VAL_UNDEF;
         }
         u64 m = ballot(ok);
         if (m) {
@@ -605,19 +616,19 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
 // ---- conflict analysis (first UIP) -----------------------------------------
 struct Learnt { int n, bt_level; uint32_t lbd; };
 
-DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, uint8_t* seen, int32_t* toclear, int32_t* learnt_buf, bool act, int q, int dl,
+DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, MsVarRec* vrec, int32_t* toclear, int32_t* learnt_buf, bool act, int q, int dl,
                        int& path_c, int& n_out, int& n_clear) {
     int v = q >> 1;
     bool fresh = false, cur = false;
     if (act) {
-        int lv = WKA(int32_t, level)[v];
-        fresh = !seen[v] && lv > 0;
+        int lv = VREC[v].level;
+        fresh = !vrec[v].seen && lv > 0;
         cur = fresh && lv >= dl;
     }
     u64 fm = ballot(fresh), cm = ballot(cur);
     u64 lm = fm & ~cm;
     if (fresh) {
-        seen[v] = 1;
+        vrec[v].seen = 1;
         toclear[n_clear + popc64(fm & lanemask_lt(w.lane))] = v;
         if (!cur) learnt_buf[n_out + popc64(lm & lanemask_lt(w.lane))] = q;
     }
@@ -627,7 +638,7 @@ DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, uint8_t* se
 }
 
 DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
-    uint8_t* seen = WK_PTR(uint8_t, w, L, seen);
+    MsVarRec* vrec = VREC;
     int32_t* toclear = WK_PTR(int32_t, w, L, toclear);
     int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
     uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
@@ -644,18 +655,18 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
             for (int k0 = 0; k0 < size; k0 += MS_WAVE) {
                 int k = k0 + w.lane;
                 int q = k < size ? cl[k] : 0;
-                analyze_visit(w, sh, L, seen, toclear, learnt_buf, k < size && q != p, q, dl, path_c, n_out, n_clear);
+                analyze_visit(w, sh, L, vrec, toclear, learnt_buf, k < size && q != p, q, dl, path_c, n_out, n_clear);
             }
         } else {
             int q = w.lane == 0 ? ba : (w.lane == 1 ? bb : bc);
-            analyze_visit(w, sh, L, seen, toclear, learnt_buf, w.lane < kind && q != p, q, dl, path_c, n_out, n_clear);
+            analyze_visit(w, sh, L, vrec, toclear, learnt_buf, w.lane < kind && q != p, q, dl, path_c, n_out, n_clear);
         }
         wave_fence();
         // walk the trail back to the most recent literal marked seen
         for (;;) {
             int i = index - w.lane;
             int l = i >= 0 ? WKA(int32_t, trail)[i] : 0;
-            bool ok = i >= 0 && seen[l >> 1];
+            bool ok = i >= 0 && vrec[l >> 1].seen;
             u64 m = ballot(ok);
             if (m) {
                 int f = first_lane(m);
@@ -668,9 +679,9 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
         }
         index--;
         const int v = p >> 1;
-        const int r = uni(WKA(int32_t, reason)[v]);
+        const int r = uni(VREC[v].reason);
         wave_fence();
-        if (w.lane == 0) seen[v] = 0;
+        if (w.lane == 0) vrec[v].seen = 0;
         wave_fence();
         path_c--;
         if (path_c <= 0) break;
@@ -693,7 +704,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
         bool act = i < n_out, keep = act;
         int q = act ? learnt_buf[i] : 0;
         if (act) {
-            int r = WKA(int32_t, reason)[q >> 1];
+            int r = VREC[q >> 1].reason;
             if (r >= 0) {
                 const int32_t* cl;
                 int size;
@@ -702,7 +713,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
                 for (int k = 0; k < size && red; k++) {
                     int l = cl[k];
                     if ((l >> 1) == (q >> 1)) continue;
-                    red = seen[l >> 1] || WKA(int32_t, level)[l >> 1] == 0;
+                    red = vrec[l >> 1].seen || VREC[l >> 1].level == 0;
                 }
                 keep = !red;
             } else if (MS_IS_TERN_REASON(r)) {
@@ -713,12 +724,12 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
                 for (int k = 0; k < 3; k++) {
                     int l = l3[k];
                     if ((l >> 1) == (q >> 1)) continue;
-                    red = red && (seen[l >> 1] || WKA(int32_t, level)[l >> 1] == 0);
+                    red = red && (vrec[l >> 1].seen || VREC[l >> 1].level == 0);
                 }
                 keep = !red;
             } else if (MS_IS_BIN_REASON(r)) {
                 int l = MS_BIN_REASON_LIT(r);
-                keep = !(seen[l >> 1] || WKA(int32_t, level)[l >> 1] == 0);
+                keep = !(vrec[l >> 1].seen || VREC[l >> 1].level == 0);
             }
         }
         u64 km = ballot(keep);
@@ -733,7 +744,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
     if (n_out > 1) {
         int best = -1, best_i = 0x7fffffff;
         for (int i = 1 + w.lane; i < n_out; i += MS_WAVE) {
-            int lv = WKA(int32_t, level)[learnt_buf[i] >> 1];
+            int lv = VREC[learnt_buf[i] >> 1].level;
             if (lv > best) { best = lv; best_i = i; }
         }
         int mx = wave_max(best);
@@ -755,7 +766,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
         for (int i0 = 0; i0 < n_out; i0 += MS_WAVE) {
             int i = i0 + w.lane;
             bool act = i < n_out;
-            int lv = act ? WKA(int32_t, level)[learnt_buf[i] >> 1] : 0;
+            int lv = act ? VREC[learnt_buf[i] >> 1].level : 0;
             uint32_t id = base + 1 + (uint32_t)i;
             bool cand = act && lvl_stamp[lv] <= base;
             wave_fence();
@@ -776,12 +787,11 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
     if (w.vm_end + n_clear > (int)L.vm_cap) vm_compact(w, sh, L);
     {
         int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
-        int32_t* vm_pos = WK_PTR(int32_t, w, L, vm_pos);
         for (int i = w.lane; i < n_clear; i += MS_WAVE) {
             int v = toclear[i];
-            seen[v] = 0;
+            vrec[v].seen = 0;
             vm_order[w.vm_end + i] = v;
-            vm_pos[v] = w.vm_end + i;
+            vrec[v].vm_pos = w.vm_end + i;
         }
     }
     w.vm_end += n_clear;
@@ -891,8 +901,8 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
             o1 = ch.start + ch.size;
             ww = WKA(int2, wl)[sh.n_orig + k];
             int cref = (int)(sh.n_orig + k);
-            bool locked = (lit_value<LV>(w, sh, L, ww.x) == MS_VAL_TRUE && WKA(int32_t, reason)[ww.x >> 1] == cref) ||
-                          (lit_value<LV>(w, sh, L, ww.y) == MS_VAL_TRUE && WKA(int32_t, reason)[ww.y >> 1] == cref);
+            bool locked = (lit_value<LV>(w, sh, L, ww.x) == MS_VAL_TRUE && VREC[ww.x >> 1].reason == cref) ||
+                          (lit_value<LV>(w, sh, L, ww.y) == MS_VAL_TRUE && VREC[ww.y >> 1].reason == cref);
             bool protect = locked || lb <= 2 || (used && lb <= 6) || (o1 - o0) <= 2;
             if (!protect) {
                 if (lb > cut) del = true;
@@ -950,8 +960,8 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
     // pass 3: reasons of assigned variables
     for (int i = w.lane; i < w.trail_n; i += MS_WAVE) {
         int v = WKA(int32_t, trail)[i] >> 1;
-        int r = WKA(int32_t, reason)[v];
-        if (r >= 0 && (uint32_t)r >= sh.n_orig) WKA(int32_t, reason)[v] = (int)(sh.n_orig + remap[(uint32_t)r - sh.n_orig]);
+        int r = VREC[v].reason;
+        if (r >= 0 && (uint32_t)r >= sh.n_orig) VREC[v].reason = (int)(sh.n_orig + remap[(uint32_t)r - sh.n_orig]);
     }
     wave_fence();
 }
@@ -1019,17 +1029,10 @@ DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const
 #ifdef MS_PROFILE
     for (int i = 0; i < PF_N; i++) w.prof[i] = 0;
 #endif
-    if (LV) {  // stage the assignment: bytes in HBM -> 2 bits per variable in LDS
-        const uint8_t* gval = WKA(uint8_t, val);
+    if (LV) {  // stage the packed assignment words in LDS for this slice
+        const uint32_t* gv = WKA(uint32_t, val);
         const uint32_t words = (sh.n_vars + 15) >> 4;
-        for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) {
-            uint32_t x = 0;
-            for (uint32_t k = 0; k < 16; k++) {
-                uint32_t v = i * 16 + k;
-                if (v < sh.n_vars) x |= ((uint32_t)gval[v] & 3u) << (2 * k);
-            }
-            w.lval[i] = x;
-        }
+        for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) w.lval[i] = gv[i];
     }
 }
 
@@ -1038,9 +1041,9 @@ DEV void wk_store(Wk& w, const MsShared& sh, const MsLayout& L, u64 cycles) {
     u64 cl = wave_sum_u32(w.c_cl_lit);
     lds_fence();
     if (LV) {
-        uint8_t* gval = WKA(uint8_t, val);
-        for (uint32_t v = (uint32_t)w.lane; v < sh.n_vars; v += MS_WAVE)
-            gval[v] = (uint8_t)((w.lval[v >> 4] >> ((v & 15) * 2)) & 3u);
+        uint32_t* gv = WKA(uint32_t, val);
+        const uint32_t words = (sh.n_vars + 15) >> 4;
+        for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) gv[i] = w.lval[i];
     }
     if (w.lane == 0) {
         MsState* s = WKA(MsState, state);
@@ -1140,7 +1143,7 @@ DEV_COLD void on_fixpoint(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         int v = pick_branch_var<LV>(w, sh, L);
         if (v < 0) { w.status = MS_ST_SAT; return; }
         w.c_dec++;
-        next = uni(2 * v + (int)WK_PTR(uint8_t, w, L, phase)[v]);
+        next = uni(2 * v + (int)VREC[v].phase);
     }
     new_decision_level(w, sh, L);
     enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);

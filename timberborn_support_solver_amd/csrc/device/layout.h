@@ -63,6 +63,9 @@ struct ms_int2 { int32_t x, y; };
 struct MsLitHdr { uint32_t bin_off, bin_n, tern_off, tern_n; };
 // Per-literal header of the private watch list: ONE 16-byte load; `size` is the atomic push counter.
 struct MsWatchHdr { uint32_t base, size, cap, pad; };
+// Per-variable record: everything BCP, backtracking and analysis touch for one variable sits in ONE
+// 16-byte slot (one 64-byte line per assignment instead of five).
+struct MsVarRec { int32_t level, reason, vm_pos; uint8_t phase, seen, pad0, pad1; };
 // Long / learnt clause header: literals start 16-byte aligned (4 literals) so that a lane reads 4 at a time.
 struct MsClauseHdr { uint32_t start, size; };
 
@@ -82,14 +85,11 @@ struct MsShared {
 struct MsLayout {
     uint64_t slab_bytes;
     uint64_t state;       // MsState
-    uint64_t val;         // uint8  [n_vars]   MS_ASG_*
-    uint64_t phase;       // uint8  [n_vars]   saved sign (1 = assign false)
-    uint64_t seen;        // uint8  [n_vars]
-    uint64_t level;       // int32  [n_vars]
-    uint64_t reason;      // int32  [n_vars]
+    uint64_t val;         // uint32 [(n_vars+15)/16]  assignment, 2 bits per variable (MS_ASG_*): the whole
+                          //        assignment of a worker is 24 KB at 64x64, so all workers' fit in L2 + Infinity Cache
+    uint64_t vrec;        // MsVarRec [n_vars]  level, reason, decision-queue position, saved phase, seen mark
     uint64_t trail;       // int32  [n_vars]
     uint64_t trail_lim;   // int32  [n_vars+1]
-    uint64_t vm_pos;      // int32  [n_vars]   index of the var's live entry in vm_order
     uint64_t vm_order;    // int32  [vm_cap]   move-to-front queue as an append-only array
     uint64_t wl;          // int2   [n_orig + learnt_cap]  the two watched literals per clause
     uint64_t whdr;        // MsWatchHdr [2*n_vars]  the literal's watch list: slot in pool, size, capacity

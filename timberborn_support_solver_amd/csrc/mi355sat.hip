@@ -85,11 +85,11 @@ __global__ void ms_customize_kernel(MsLayout L, char* slabs, uint32_t n_workers,
             if (a >= n) a = 1;
         }
         int32_t* order = (int32_t*)(slab + L.vm_order);
-        int32_t* pos = (int32_t*)(slab + L.vm_pos);
+        MsVarRec* vrec = (MsVarRec*)(slab + L.vrec);
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
             uint32_t v = (uint32_t)(((uint64_t)a * i + b) % n);
             order[i] = (int32_t)v;
-            pos[v] = (int32_t)i;
+            vrec[v].vm_pos = (int32_t)i;
         }
     }
 }
@@ -379,14 +379,10 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     size_t off = 0;
     auto place = [&](uint64_t& field, size_t bytes) { field = off; off = align_up(off + bytes, 256); };
     place(L.state, sizeof(MsState));
-    place(L.val, nv);
-    place(L.phase, nv);
-    place(L.seen, nv);
-    place(L.level, 4 * (size_t)nv);
-    place(L.reason, 4 * (size_t)nv);
+    place(L.val, 4 * (((size_t)nv + 15) / 16));
+    place(L.vrec, sizeof(MsVarRec) * (size_t)nv);
     place(L.trail, 4 * (size_t)nv);
     place(L.trail_lim, 4 * ((size_t)nv + 1));
-    place(L.vm_pos, 4 * (size_t)nv);
     place(L.vm_order, 4 * (size_t)L.vm_cap);
     place(L.wl, 8 * ((size_t)no + L.learnt_cap));
     place(L.whdr, sizeof(MsWatchHdr) * 2 * (size_t)nv);
@@ -418,19 +414,19 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     st->pool_top = (uint32_t)pool_need;
     s.pool_init = pool_need;
     st->next_reduce = s.opts.reduce_first > 0 ? (uint64_t)s.opts.reduce_first : 2000;
-    memset(T + L.val, MS_ASG_UNDEF, nv);
-    memset(T + L.phase, 1, nv);
-    int32_t* reason = (int32_t*)(T + L.reason);
-    for (uint32_t v = 0; v < nv; v++) reason[v] = MS_REASON_NONE;
+    uint32_t* val = (uint32_t*)(T + L.val);      // zero = every variable unassigned
+    MsVarRec* vrec = (MsVarRec*)(T + L.vrec);
+    int32_t* vm_order = (int32_t*)(T + L.vm_order);
+    for (uint32_t v = 0; v < nv; v++) {
+        vrec[v] = MsVarRec{0, MS_REASON_NONE, (int32_t)(nv - 1 - v), /*phase=*/1, /*seen=*/0, 0, 0};
+        vm_order[nv - 1 - v] = (int32_t)v;
+    }
     int32_t* trail = (int32_t*)(T + L.trail);
     for (size_t i = 0; i < P.units.size(); i++) {
         int32_t l = P.units[i];
         trail[i] = l;
-        ((uint8_t*)(T + L.val))[l >> 1] = (uint8_t)(2 | (l & 1));
+        val[(l >> 1) >> 4] |= (2u | (uint32_t)(l & 1)) << (((l >> 1) & 15) * 2);
     }
-    int32_t* vm_pos = (int32_t*)(T + L.vm_pos);
-    int32_t* vm_order = (int32_t*)(T + L.vm_order);
-    for (uint32_t v = 0; v < nv; v++) { vm_order[nv - 1 - v] = (int32_t)v; vm_pos[v] = (int32_t)(nv - 1 - v); }
     int2* wl = (int2*)(T + L.wl);
     MsWatchHdr* whdr = (MsWatchHdr*)(T + L.whdr);
     int2* pool = (int2*)(T + L.pool);
@@ -552,14 +548,16 @@ void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
     }
 }
 
+inline uint8_t asg_of(const uint32_t* words, uint64_t v) { return (uint8_t)((words[v >> 4] >> ((v & 15) * 2)) & 3u); }
+
 void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_t n_vars_out) {
-    std::vector<uint8_t> val(s.n_vars);
+    std::vector<uint32_t> words(((size_t)s.n_vars + 15) / 16 + 1);
     if (s.n_vars)
-        HIPCHK(hipMemcpy(val.data(), s.d_slabs.p + (size_t)worker * s.L.slab_bytes + s.L.val, s.n_vars,
-                         hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(words.data(), s.d_slabs.p + (size_t)worker * s.L.slab_bytes + s.L.val,
+                         4 * (((size_t)s.n_vars + 15) / 16), hipMemcpyDeviceToHost));
     out.assign(n_vars_out, 0);
     for (uint64_t v = 0; v < n_vars_out && v < s.n_vars; v++)
-        out[v] = val[v] == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
+        out[v] = asg_of(words.data(), v) == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
 }
 
 struct SliceResult { float ms; };
@@ -776,8 +774,8 @@ int sweep_step(mi355sat& s, Sweep& sw) {
     }
     sw.conflicts = confl;
     if (s.opts.verbose) {
-        uint64_t props = 0, nl = 0, ll = 0, busy = 0;
-        for (auto& st : sw.sts) { props += st.propagations; nl += st.n_learnts; ll += st.lc_lits_n; }
+        uint64_t props = 0, nl = 0, busy = 0;
+        for (auto& st : sw.sts) { props += st.propagations; nl += st.n_learnts; }
         for (auto b : sw.w_busy) busy += b;
         fprintf(stderr, "[mi355sat] slice: decided %u/%u conflicts=%llu props=%llu kernel=%.3fs busy=%llu/%u splits=%llu closed=%llu kept=%llu\n",
                 sw.decided, n_instances, (unsigned long long)confl, (unsigned long long)props, s.stats.kernel_seconds,
@@ -1070,13 +1068,14 @@ int mi355sat_propagate_batch(mi355sat* s, const int32_t* decisions, const uint64
             }
         }
         if (out_values) {
-            std::vector<uint8_t> raw(n_instances * (size_t)P.n_vars);
+            const size_t nw = ((size_t)P.n_vars + 15) / 16;
+            std::vector<uint32_t> raw(n_instances * nw + 1);
             if (P.n_vars)
-                HIPCHK(hipMemcpy2D(raw.data(), P.n_vars, s->d_slabs.p + s->L.val, s->L.slab_bytes, P.n_vars,
+                HIPCHK(hipMemcpy2D(raw.data(), 4 * nw, s->d_slabs.p + s->L.val, s->L.slab_bytes, 4 * nw,
                                    n_instances, hipMemcpyDeviceToHost));
             for (uint64_t i = 0; i < n_instances; i++)
                 for (uint64_t v = 0; v < n_vars; v++) {
-                    uint8_t x = v < P.n_vars ? raw[i * P.n_vars + v] : MS_ASG_UNDEF;
+                    uint8_t x = v < P.n_vars ? asg_of(raw.data() + i * nw, v) : MS_ASG_UNDEF;
                     out_values[i * n_vars + v] = x == MS_ASG_TRUE ? 1 : (x == MS_ASG_FALSE ? -1 : 0);
                 }
         }
