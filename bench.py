@@ -52,11 +52,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the solver has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    # BENCH_BACKEND=gloo + BENCH_DEVICE=0 rehearse the N>1 path with several ranks on ONE GPU
+    # (RCCL refuses two ranks per device); the driver's runs use nccl (= RCCL) with one rank per GPU.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    device_index = int(os.environ.get("BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device_index)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     from timberborn_support_solver_amd import (PLATFORMS_DEFAULT, Encoding, Mi355Sat, PlatformLimits, SolverResult,
                                                WorldGrid, algorithmic_bytes)
@@ -72,7 +80,7 @@ def main():
     assumption_sets = [([-int(outs[k])] if k < args.k_hi else []) for k in ks]
     workers = max(len(ks), args.workers // len(ks) * len(ks))
 
-    solver = Mi355Sat(device=local_rank, workers=workers, slice_ms=args.slice_ms, seed=1000 + rank)
+    solver = Mi355Sat(device=device_index, workers=workers, slice_ms=args.slice_ms, seed=1000 + rank)
     solver.add_cnf(cnf.lits, cnf.offsets)
     solver.reserve(cnf.n_vars)
     solver.sweep_begin(assumption_sets)  # upload + replicate: everything resident in HBM from here on
@@ -82,7 +90,7 @@ def main():
         sat_k = min([k for k, r in zip(ks, results) if r == SolverResult.Sat], default=1 << 30)
         unsat_k = max([k for k, r in zip(ks, results) if r == SolverResult.Unsat], default=-1)
         if dist is not None:
-            t = torch.tensor([-sat_k, unsat_k], dtype=torch.int64, device="cuda")
+            t = torch.tensor([-sat_k, unsat_k], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sat_k, unsat_k = -int(t[0]), int(t[1])
         return sat_k, unsat_k
@@ -112,9 +120,9 @@ def main():
     alg_bytes = algorithmic_bytes(d)
     tot = [float(props), dt, float(d["conflicts"])]
     if dist is not None:
-        t = torch.tensor([float(props), float(d["conflicts"])], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(props), float(d["conflicts"])], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        tm = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tm = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         tot = [float(t[0]), float(tm[0]), float(t[1])]
     total_props, max_dt, total_confl = tot
@@ -151,7 +159,7 @@ def main():
         c2 = e2.with_limits_into_cnf(PlatformLimits({(1, 1): k0}), sweep=True)
         ks2 = list(range(k0, -1, -1))
         sets2 = [([-int(c2.card_outputs[k])] if k < k0 else []) for k in ks2]
-        sv = Mi355Sat(device=local_rank, workers=max(len(ks2), 3072 // len(ks2) * len(ks2)), slice_ms=10)
+        sv = Mi355Sat(device=device_index, workers=max(len(ks2), 3072 // len(ks2) * len(ks2)), slice_ms=10)
         sv.add_cnf(c2.lits, c2.offsets)
         tg = time.perf_counter()
         sv.sweep_begin(sets2)

@@ -67,7 +67,7 @@ typedef struct mi355sat_opts {
     int32_t reduce_first;      /* conflicts before the first learnt-clause reduction; 0 = 2000 */
     int32_t reduce_inc;        /* growth of the reduction interval; 0 = 300 */
     int32_t lds_val;           /* assignment in LDS (2 bits/var): 0 auto, 1 force, -1 never */
-    int32_t max_groups;        /* queue literals propagated per BCP step: 1..8; 0 = 8 */
+    int32_t max_groups;        /* queue literals propagated per BCP step: 1..16; 0 = 16 */
     int32_t slice_ms;          /* wall-time bound of one kernel launch in ms (all workers stop together); 0 = 20 */
     int32_t cube_split;        /* 0 (default): portfolio, every worker of an instance searches the whole instance with its
                                   own decision order; 1: idle workers steal sub-cubes of running ones between slices
@@ -94,7 +94,7 @@ typedef struct mi355sat_stats_t {
     uint64_t kernel_launches;
     uint64_t n_deq, n_watch, n_cl_lit, n_move, n_enq;
     uint64_t n_sat, n_unsat, n_terminated; /* rustsat SolverStats: results returned so far */
-    uint64_t bcp_steps;        /* BCP steps; each propagates up to 8 queue literals (one per lane group) */
+    uint64_t bcp_steps;        /* BCP steps; each propagates up to 16 queue literals (one per lane group) */
     uint64_t bcp_requeued;     /* literals re-queued because two groups met in one clause */
     uint64_t reserved[6];
 } mi355sat_stats_t;

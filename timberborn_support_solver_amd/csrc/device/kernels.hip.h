@@ -310,8 +310,8 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         PROF_DECL
         // ---- split the wave into G groups of S lanes, one queue literal per group
         const int qlen = w.trail_n - w.qhead;
-        int lg = qlen >= 8 ? 3 : (qlen >= 4 ? 2 : (qlen >= 2 ? 1 : 0));
-        if ((1 << lg) > w.max_groups) lg = w.max_groups >= 4 ? 2 : (w.max_groups >= 2 ? 1 : 0);
+        int lg = qlen >= 16 ? 4 : (qlen >= 8 ? 3 : (qlen >= 4 ? 2 : (qlen >= 2 ? 1 : 0)));
+        while ((1 << lg) > w.max_groups) lg--;
         const int G = 1 << lg, S = MS_WAVE >> lg;
         const int g = w.lane >> (6 - lg), sl = w.lane & (S - 1);
         const u64 gmask = (S == MS_WAVE ? ~0ull : ((1ull << S) - 1ull)) << (g * S);

@@ -22,7 +22,7 @@
 #define MS_CLAIM_SLOTS 128        // per-wave implication claim table in LDS
 #define MS_OVERFLOW_CAP 192       // watcher pushes that found their list full, per chunk
 #define MS_LBDQ 50                // Glucose restart window
-#define MS_MAX_GROUPS 8           // queue literals propagated per step (lane groups per wave)
+#define MS_MAX_GROUPS 16          // queue literals propagated per step (lane groups per wave)
 #define MS_SPLIT_MAX 8            // decisions a worker offers per slice for splitting its cube
 
 // lit_value() results
