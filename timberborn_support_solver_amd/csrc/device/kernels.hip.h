@@ -180,59 +180,68 @@ DEV void enqueue_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int lit, 
     lds_fence();
 }
 
-// Lanes with `want` each imply literal q with reason `reason` (a cref, or a
-// binary / ternary reason code).  Several lanes may imply the same literal (keep
-// one) or complementary literals (conflict).  One LDS claim per variable decides.
-// A lane whose implication turned out to be falsified reports it through `lost`.
+// ---- implication arbitration ---------------------------------------------------------
+// Lanes of one step may imply the same literal (keep one) or complementary literals
+// (conflict).  An exact claim set in LDS (open addressing on the variable, one CAS per probe)
+// decides; it is cleared at the start of every commit round.
+enum { CLAIM_NONE = 0, CLAIM_WON = 1, CLAIM_DUP = 2, CLAIM_LOST = 3 };
+
+DEV void claims_clear(Wk& w) {
+#pragma unroll
+    for (int k = 0; k < MS_CLAIM_SLOTS / MS_WAVE; k++) w.claim[w.lane + MS_WAVE * k] = 0;
+    lds_fence();
+}
+
+DEV int claim_insert(Wk& w, bool want, int q) {
+    if (!want) return CLAIM_NONE;
+    const uint32_t key = ((uint32_t)(q + 1) << 6) | (uint32_t)w.lane;
+    uint32_t slot = (((uint32_t)(q >> 1) * 2654435761u) >> 20) & (MS_CLAIM_SLOTS - 1);
+    for (;;) {
+        const uint32_t old = atomicCAS((uint32_t*)&w.claim[slot], 0u, key);
+        if (old == 0) return CLAIM_WON;
+        const uint32_t oq = (old >> 6) - 1;
+        if ((oq >> 1) == (uint32_t)(q >> 1)) return oq == (uint32_t)q ? CLAIM_DUP : CLAIM_LOST;
+        slot = (slot + 1) & (MS_CLAIM_SLOTS - 1);
+    }
+}
+
+// Winners append their literal to the trail (prefix popcount) and record level / reason.
+template <bool LV>
+DEV void assign_winners(Wk& w, const MsShared& sh, const MsLayout& L, bool won, int q, int reason) {
+    const u64 wm = ballot(won);
+    if (wm == 0) return;
+    if (won) {
+        const int v = q >> 1;
+        const int t = w.trail_n + popc64(wm & lanemask_lt(w.lane));
+        asg_set<LV>(w, sh, L, q);
+        VREC[v].level = w.n_levels;
+        VREC[v].reason = reason;
+        WKA(int32_t, trail)[t] = q;
+        w.ring[t & (MS_LDS_RING - 1)] = q;
+    }
+    const int nw = popc64(wm);
+    w.trail_n += nw;
+    w.c_enq += (uint32_t)nw;
+    ring_note_growth(w, sh, L);
+}
+
+// One candidate per lane (later chunks of a list).  `lost`: my implication is already falsified.
 template <bool LV>
 DEV void commit_implications(Wk& w, const MsShared& sh, const MsLayout& L, bool want, int q, int reason, bool& lost) {
     lost = false;
-    u64 m = ballot(want);
+    const u64 m = ballot(want);
     if (m == 0) return;
     if ((m & (m - 1)) == 0) {  // single implication: no arbitration needed
-        if (want) {
-            int v = q >> 1;
-            asg_set<LV>(w, sh, L, q);
-            VREC[v].level = w.n_levels;
-            VREC[v].reason = reason;
-            WKA(int32_t, trail)[w.trail_n] = q;
-            w.ring[w.trail_n & (MS_LDS_RING - 1)] = q;
-        }
-        w.trail_n++;
-        w.c_enq++;
-        ring_note_growth(w, sh, L);
+        assign_winners<LV>(w, sh, L, want, q, reason);
         lds_fence();
         return;
     }
-    const uint32_t slot = (((uint32_t)(q >> 1) * 2654435761u) >> 20) & (MS_CLAIM_SLOTS - 1);
-    while (m) {
-        if (want) w.claim[slot] = ((uint32_t)q << 6) | (uint32_t)w.lane;
-        lds_fence();
-        bool won = false;
-        if (want) {
-            uint32_t c = w.claim[slot];
-            int cq = (int)(c >> 6), cl = (int)(c & 63);
-            if (cl == w.lane) { won = true; want = false; }
-            else if (cq == q) want = false;                      // same literal implied twice
-            else if (cq == (q ^ 1)) { lost = true; want = false; }  // complementary: my clause is now falsified
-        }
-        u64 wm = ballot(won);
-        if (won) {
-            int v = q >> 1;
-            int t = w.trail_n + popc64(wm & lanemask_lt(w.lane));
-            asg_set<LV>(w, sh, L, q);
-            VREC[v].level = w.n_levels;
-            VREC[v].reason = reason;
-            WKA(int32_t, trail)[t] = q;
-            w.ring[t & (MS_LDS_RING - 1)] = q;
-        }
-        int nw = popc64(wm);
-        w.trail_n += nw;
-        w.c_enq += (uint32_t)nw;
-        ring_note_growth(w, sh, L);
-        lds_fence();
-        m = ballot(want);
-    }
+    claims_clear(w);
+    const int c = claim_insert(w, want, q);
+    lds_fence();
+    lost = c == CLAIM_LOST;
+    assign_winners<LV>(w, sh, L, c == CLAIM_WON, q, reason);
+    lds_fence();
 }
 
 // ---- watch lists -------------------------------------------------------
@@ -273,25 +282,103 @@ DEV void repair_overflow(Wk& w, const MsShared& sh, const MsLayout& L) {
     lds_fence();
 }
 
-// Find a non-false literal of clause `cl[0..size)` other than fl / other: 4 literals per load
-// (clause literals are 16-byte aligned), the first `MS_LANE_SCAN` by the visiting lane itself.
+// ---- one watcher of a long / learnt clause ---------------------------------------------
 #define MS_LANE_SCAN 8
+struct LongRes {
+    int2 wt;            // watcher to keep (blocker possibly updated)
+    bool live, keep, want, cf, deferred;
+    int imp;            // implied literal if want
+};
+
+DEV MsClauseHdr clause_hdr_of(const Wk& w, const MsShared& sh, const MsLayout& L, int c) {
+    return (uint32_t)c < sh.n_orig ? sh.cl_hdr[c] : WKA(MsClauseHdr, lc_hdr)[(uint32_t)c - sh.n_orig];
+}
+
+// Visit watcher `wt` of the false literal `fl`.  vbl / ww / ch are the blocker's value, the clause's
+// watched pair and its header, loaded speculatively by the caller together with everything else the
+// step needs (one round trip).  All values are a snapshot taken before the step's commit.  Must be
+// called by all 64 lanes (phase B is wave-cooperative).
 template <bool LV>
-DEV int scan_head(const Wk& w, const MsShared& sh, const MsLayout& L, const int32_t* cl, int size, int fl, int other,
-                  uint32_t& nl) {
-    const int lim = size < MS_LANE_SCAN ? size : MS_LANE_SCAN;
-    for (int k = 0; k < lim; k += 4) {
-        const int4 q = *(const int4*)(cl + k);
-        const int ls[4] = {q.x, q.y, q.z, q.w};
+DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, bool live, int vbl, int2 ww, MsClauseHdr ch,
+                      int fl, int g, const int (&bf)[MS_MAX_GROUPS]) {
+    LongRes R;
+    R.wt = wt; R.live = live; R.keep = live; R.want = false; R.cf = false; R.deferred = false; R.imp = 0;
+    bool scanning = false, need_tail = false;
+    int other = 0, vo = MS_VAL_TRUE, r = -1;
+    const int size = (int)ch.size;
+    const int32_t* cl = ((uint32_t)wt.x < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + ch.start;
+    uint32_t nl = 0;
+    if (live && vbl != MS_VAL_TRUE) {
+        other = (ww.x == fl) ? ww.y : ww.x;
+        // the other watch and the first 8 literals: two 16-byte loads + their values, issued together
+        const int4 qa = *(const int4*)cl;
+        const int4 qb = size > 4 ? *(const int4*)(cl + 4) : make_int4(fl, fl, fl, fl);
+        vo = lit_value<LV>(w, sh, L, other);
+        const int ls[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        int vs[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int l = ls[u];
-            if (k + u >= size || l == fl || l == other) continue;
-            nl++;
-            if (lit_value<LV>(w, sh, L, l) != MS_VAL_FALSE) return l;
+        for (int u = 0; u < 8; u++) vs[u] = (u < size && ls[u] != fl && ls[u] != other) ? lit_value<LV>(w, sh, L, ls[u]) : MS_VAL_FALSE;
+        nl = 2;
+        if (vo == MS_VAL_TRUE) R.wt.y = other;
+        else {
+            // both watches false and the other one is being propagated by another group in
+            // this very step: the lower group handles the clause, the higher one re-queues
+            bool other_lower = false;
+            if (vo == MS_VAL_FALSE) {
+#pragma unroll
+                for (int gg = 0; gg < MS_MAX_GROUPS; gg++) other_lower = other_lower || (gg < g && bf[gg] == other);
+            }
+            if (other_lower) R.deferred = true;
+            else {
+                R.wt.y = other;
+                scanning = true;
+#pragma unroll
+                for (int u = 7; u >= 0; u--)
+                    if (vs[u] != MS_VAL_FALSE) r = ls[u];
+                nl += (uint32_t)(size < MS_LANE_SCAN ? size : MS_LANE_SCAN);
+                need_tail = r < 0 && size > MS_LANE_SCAN;
+            }
         }
     }
-    return -1;
+    // phase B (whole wave, one clause at a time): the tail of long clauses, 64 literals per load
+    for (u64 tm = ballot(need_tail); tm != 0; tm &= tm - 1) {
+        const int f = first_lane(tm);
+        const unsigned long long cp = (unsigned long long)cl;
+        const int32_t* clf = (const int32_t*)(((unsigned long long)(uint32_t)bcast((int)(cp >> 32), f) << 32) |
+                                              (unsigned long long)(uint32_t)bcast((int)cp, f));
+        const int szf = bcast(size, f), flf = bcast(fl, f), of = bcast(other, f);
+        int found = -1;
+        for (int k0 = MS_LANE_SCAN; k0 < szf && found < 0; k0 += MS_WAVE) {
+            const int k = k0 + w.lane;
+            const int l = k < szf ? clf[k] : flf;
+            const bool ok = k < szf && l != flf && l != of && lit_value<LV>(w, sh, L, l) != MS_VAL_FALSE;
+            const u64 om = ballot(ok);
+            if (om) found = bcast(l, first_lane(om));
+        }
+        if (w.lane == f) { r = found; nl += (uint32_t)(szf - MS_LANE_SCAN); }
+    }
+    // phase C (per lane): move the watch, or report unit / conflict
+    if (scanning) {
+        if (r >= 0) {
+            MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
+            WKA(int2, wl)[wt.x] = make_int2(other, r);
+            const int t = r ^ 1;
+            const uint32_t pos = atomicAdd(&whdr[t].size, 1u);
+            const MsWatchHdr th = whdr[t];
+            if (pos < th.cap) WKA(int2, pool)[th.base + pos] = R.wt;
+            else {
+                uint32_t o = atomicAdd((uint32_t*)w.ov_cnt, 1u);
+                int32_t* ov = WK_PTR(int32_t, w, L, overflow);
+                ov[3 * o] = t;
+                ov[3 * o + 1] = wt.x;
+                ov[3 * o + 2] = other;
+            }
+            R.keep = false;
+        } else if (vo == MS_VAL_FALSE) R.cf = true;
+        else { R.want = true; R.imp = other; }
+    }
+    w.c_cl_lit += nl;
+    return R;
 }
 
 // Unit propagation to fixpoint.  Returns true on conflict (w.confl_*).
@@ -300,7 +387,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
     w.confl_kind = 0;
     MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
     int2* pool = WKA(int2, pool);
-    int2* wl = WKA(int2, wl);
+    const int2* wl = WKA(int2, wl);
     const int32_t* trail = WKA(int32_t, trail);
     // headers prefetched for the NEXT step (queue literal index pf_idx), loaded while this step runs
     int pf_idx = -1, pf_p = 0;
@@ -330,10 +417,11 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const uint32_t b0 = lh.bin_off, nb = lh.bin_n, t0 = lh.tern_off, nt = lh.tern_n;
         const uint32_t wb = wh.base;
         const int n = (int)wh.size;
-        // first chunk of all three lists in one round trip
-        int q0 = (uint32_t)sl < nb ? sh.bin_lits[b0 + sl] : 0;
-        int2 pr0 = (uint32_t)sl < nt ? ((const int2*)sh.tern_pairs)[t0 + sl] : make_int2(0, 0);
-        int2 wt0 = sl < n ? pool[wb + sl] : make_int2(-1, 0);
+        // round trip 1: the first chunk of all three lists
+        const bool act_b = (uint32_t)sl < nb, act_t = (uint32_t)sl < nt;
+        const int q0 = act_b ? sh.bin_lits[b0 + sl] : 0;
+        const int2 pr0 = act_t ? ((const int2*)sh.tern_pairs)[t0 + sl] : make_int2(0, 0);
+        const int2 wt0 = sl < n ? pool[wb + sl] : make_int2(-1, 0);
         {   // prefetch the headers the next step will most likely use (same split, next G queue literals)
             const int nidx = qbase + G + g;
             pf_idx = -1;
@@ -347,163 +435,147 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         w.qhead += G;
         w.c_props += (uint32_t)G;
         w.c_steps++;
-        bool lost;
-        // the false literals of all groups of this step (uniform registers), for the clash test below
+        // the false literals of all groups of this step (uniform registers), for the clash test
         int bf[MS_MAX_GROUPS];
 #pragma unroll
         for (int gg = 0; gg < MS_MAX_GROUPS; gg++) bf[gg] = gg < G ? __shfl(fl, gg * S, 64) : -1;
+        // round trip 2: ONE snapshot of every value the first chunks need, plus (speculatively) the
+        // watched pair and the header of every live watcher's clause
+        const bool live0 = sl < n && wt0.x >= 0;
+        const int vq = act_b ? lit_value<LV>(w, sh, L, q0) : MS_VAL_TRUE;
+        const int vb = act_t ? lit_value<LV>(w, sh, L, pr0.x) : MS_VAL_TRUE;
+        const int vc = act_t ? lit_value<LV>(w, sh, L, pr0.y) : MS_VAL_TRUE;
+        const int vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
+        const int2 ww0 = live0 ? wl[wt0.x] : make_int2(0, 0);
+        const MsClauseHdr ch0 = live0 ? clause_hdr_of(w, sh, L, wt0.x) : MsClauseHdr{0, 0};
         PROF_MARK(PF_OFF);
-        // ---- binary implications ------------------------------------------
-        for (uint32_t it = 0; ballot(it * S < nb) != 0; it++) {
+        // evaluate binary + ternary entries on the snapshot
+        const bool cf_b = vq == MS_VAL_FALSE, want_b = vq == MS_VAL_UNDEF;
+        const bool sat_t = vb == MS_VAL_TRUE || vc == MS_VAL_TRUE;
+        const bool cf_t = !sat_t && vb == MS_VAL_FALSE && vc == MS_VAL_FALSE;
+        const bool want_t = !sat_t && !cf_t && (vb == MS_VAL_FALSE || vc == MS_VAL_FALSE);
+        const int imp_t = vb == MS_VAL_FALSE ? pr0.y : pr0.x;
+        w.c_watch += (uint32_t)(popc64(ballot(act_b)) + popc64(ballot(act_t)) + popc64(ballot(live0)));
+        PROF_MARK(PF_BIN);
+        // first chunk of the watch lists (round trips 3..: other watch + clause literals, pushes)
+        int j = 0, done = 0, defer_g = MS_MAX_GROUPS;
+        LongRes R0 = long_eval<LV>(w, sh, L, wt0, live0, vbl0, ww0, ch0, fl, g, bf);
+        PROF_MARK(PF_LONG);
+        // ONE commit for the whole first chunk: binary, ternary and watched-clause implications
+        bool any_cf;
+        {
+            claims_clear(w);
+            const int cb = claim_insert(w, want_b, q0);
+            const int ct = claim_insert(w, want_t, imp_t);
+            const int cl3 = claim_insert(w, R0.want, R0.imp);
+            lds_fence();
+            assign_winners<LV>(w, sh, L, cb == CLAIM_WON, q0, MS_REASON_BIN(fl));
+            assign_winners<LV>(w, sh, L, ct == CLAIM_WON, imp_t, MS_REASON_TERN(t0 + sl));
+            assign_winners<LV>(w, sh, L, cl3 == CLAIM_WON, R0.imp, wt0.x);
+            lds_fence();
+            const bool xb = cf_b || cb == CLAIM_LOST, xt = cf_t || ct == CLAIM_LOST, xl = R0.cf || cl3 == CLAIM_LOST;
+            const u64 cm = ballot(xb || xt || xl);
+            any_cf = cm != 0;
+            if (any_cf) {
+                const int f = first_lane(cm);
+                const int kind = bcast(xb ? 2 : (xt ? 3 : 1), f);
+                w.confl_kind = kind;
+                w.confl_cref = bcast(wt0.x, f);
+                w.confl_a = bcast(fl, f);
+                w.confl_b = bcast(kind == 2 ? q0 : pr0.x, f);
+                w.confl_c = bcast(pr0.y, f);
+            }
+        }
+        {   // in-place compaction of the first chunk of each group's watch list
+            w.c_move += (uint32_t)popc64(ballot(R0.live && !R0.keep));
+            const u64 km = ballot(R0.keep);
+            wave_fence();
+            const int d = popc64(km & gmask & lanemask_lt(w.lane));
+            if (R0.keep && (d != sl || R0.wt.y != wt0.y)) pool[wb + d] = R0.wt;
+            j = popc64(km & gmask);
+            done = min(n, S);
+            const u64 dm = ballot(R0.deferred);
+            if (dm) defer_g = first_lane(dm) >> (6 - lg);
+            repair_overflow(w, sh, L);
+        }
+        PROF_MARK(PF_TERN);
+        bool lost;
+        // ---- remaining chunks of long binary lists -------------------------
+        for (uint32_t it = 1; !any_cf && ballot(it * S < nb) != 0; it++) {
             const uint32_t i = it * S + (uint32_t)sl;
             const bool act = i < nb;
-            const int q = it == 0 ? q0 : (act ? sh.bin_lits[b0 + i] : 0);
-            const int vq = act ? lit_value<LV>(w, sh, L, q) : MS_VAL_TRUE;
+            const int q = act ? sh.bin_lits[b0 + i] : 0;
+            const int v = act ? lit_value<LV>(w, sh, L, q) : MS_VAL_TRUE;
             w.c_watch += (uint32_t)popc64(ballot(act));
-            commit_implications<LV>(w, sh, L, vq == MS_VAL_UNDEF, q, MS_REASON_BIN(fl), lost);
-            const u64 cm = ballot(vq == MS_VAL_FALSE || lost);
+            commit_implications<LV>(w, sh, L, v == MS_VAL_UNDEF, q, MS_REASON_BIN(fl), lost);
+            const u64 cm = ballot(v == MS_VAL_FALSE || lost);
             if (cm) {
                 const int f = first_lane(cm);
+                any_cf = true;
                 w.confl_kind = 2;
                 w.confl_a = bcast(fl, f);
                 w.confl_b = bcast(q, f);
-                w.qhead = w.trail_n;
-                return true;
             }
         }
-        PROF_MARK(PF_BIN);
-        // ---- ternary clauses: literal pairs, shared and read-only ---------
-        for (uint32_t it = 0; ballot(it * S < nt) != 0; it++) {
+        // ---- remaining chunks of long ternary lists ------------------------
+        for (uint32_t it = 1; !any_cf && ballot(it * S < nt) != 0; it++) {
             const uint32_t i = it * S + (uint32_t)sl;
             const bool act = i < nt;
-            const int2 pr = it == 0 ? pr0 : (act ? ((const int2*)sh.tern_pairs)[t0 + i] : make_int2(0, 0));
-            const int vb = act ? lit_value<LV>(w, sh, L, pr.x) : MS_VAL_TRUE;
-            const int vc = act ? lit_value<LV>(w, sh, L, pr.y) : MS_VAL_TRUE;
+            const int2 pr = act ? ((const int2*)sh.tern_pairs)[t0 + i] : make_int2(0, 0);
+            const int xb = act ? lit_value<LV>(w, sh, L, pr.x) : MS_VAL_TRUE;
+            const int xc = act ? lit_value<LV>(w, sh, L, pr.y) : MS_VAL_TRUE;
             w.c_watch += (uint32_t)popc64(ballot(act));
-            const bool sat = vb == MS_VAL_TRUE || vc == MS_VAL_TRUE;
-            const bool cf = !sat && vb == MS_VAL_FALSE && vc == MS_VAL_FALSE;
-            const bool want = !sat && !cf && (vb == MS_VAL_FALSE || vc == MS_VAL_FALSE);
-            const int imp = vb == MS_VAL_FALSE ? pr.y : pr.x;
+            const bool sat = xb == MS_VAL_TRUE || xc == MS_VAL_TRUE;
+            const bool cf = !sat && xb == MS_VAL_FALSE && xc == MS_VAL_FALSE;
+            const bool want = !sat && !cf && (xb == MS_VAL_FALSE || xc == MS_VAL_FALSE);
+            const int imp = xb == MS_VAL_FALSE ? pr.y : pr.x;
             commit_implications<LV>(w, sh, L, want, imp, MS_REASON_TERN(t0 + i), lost);
             const u64 cm = ballot(cf || lost);
             if (cm) {
                 const int f = first_lane(cm);
+                any_cf = true;
                 w.confl_kind = 3;
                 w.confl_a = bcast(fl, f);
                 w.confl_b = bcast(pr.x, f);
                 w.confl_c = bcast(pr.y, f);
-                w.qhead = w.trail_n;
-                return true;
             }
         }
-        PROF_MARK(PF_TERN);
-        // ---- long + learnt clauses: two watched literals ------------------
-        int j = 0;          // kept watchers of my group's list so far
-        int done = 0;       // list entries of my group's list already visited
-        int defer_g = MS_MAX_GROUPS;
-        for (int it = 0; ballot(it * S < n) != 0; it++) {
+        // ---- remaining chunks of the watch lists ----------------------------
+        for (int it = 1; !any_cf && w.status == MS_ST_RUNNING && ballot(it * S < n) != 0; it++) {
             const int i = it * S + sl;
             const bool act = i < n;
-            int2 wt = it == 0 ? wt0 : (act ? pool[wb + i] : make_int2(-1, 0));
-            const int blocker0 = wt.y;
-            const bool live = act && wt.x >= 0;       // cref < 0: tombstone left by an interrupted pass
-            bool keep = live, want = false, cf = false, deferred = false;
-            // phase A (per lane): blocker, the other watch, the first literals of the clause
-            bool scanning = false, need_tail = false;
-            int other = 0, vo = MS_VAL_TRUE, r = -1, size = 0;
-            const int32_t* cl = nullptr;
-            uint32_t nl = 0;
-            if (live && lit_value<LV>(w, sh, L, wt.y) != MS_VAL_TRUE) {
-                const int2 ww = wl[wt.x];
-                other = (ww.x == fl) ? ww.y : ww.x;
-                vo = lit_value<LV>(w, sh, L, other);
-                nl = 2;
-                if (vo == MS_VAL_TRUE) wt.y = other;
-                else {
-                    // both watches false and the other one is being propagated by another group in
-                    // this very step: the lower group handles the clause, the higher one re-queues
-                    bool other_lower = false;
-                    if (vo == MS_VAL_FALSE) {
-#pragma unroll
-                        for (int gg = 0; gg < MS_MAX_GROUPS; gg++) other_lower = other_lower || (gg < g && bf[gg] == other);
-                    }
-                    if (other_lower) deferred = true;
-                    else {
-                        wt.y = other;
-                        scanning = true;
-                        clause_range(w, sh, L, wt.x, cl, size);
-                        r = scan_head<LV>(w, sh, L, cl, size, fl, other, nl);
-                        need_tail = r < 0 && size > MS_LANE_SCAN;
-                    }
-                }
-            }
-            // phase B (whole wave, one clause at a time): the tail of long clauses, 64 literals per load
-            for (u64 tm = ballot(need_tail); tm != 0; tm &= tm - 1) {
-                const int f = first_lane(tm);
-                const unsigned long long cp = (unsigned long long)cl;
-                const int32_t* clf = (const int32_t*)(((unsigned long long)(uint32_t)bcast((int)(cp >> 32), f) << 32) |
-                                                      (unsigned long long)(uint32_t)bcast((int)cp, f));
-                const int szf = bcast(size, f), flf = bcast(fl, f), of = bcast(other, f);
-                int found = -1;
-                for (int k0 = MS_LANE_SCAN; k0 < szf && found < 0; k0 += MS_WAVE) {
-                    const int k = k0 + w.lane;
-                    const int l = k < szf ? clf[k] : flf;
-                    const bool ok = k < szf && l != flf && l != of && lit_value<LV>(w, sh, L, l) != MS_VAL_FALSE;
-                    const u64 om = ballot(ok);
-                    if (om) found = bcast(l, first_lane(om));
-                }
-                if (w.lane == f) { r = found; nl += (uint32_t)(szf - MS_LANE_SCAN); }
-            }
-            // phase C (per lane): move the watch, or report unit / conflict
-            int imp = 0;
-            if (scanning) {
-                if (r >= 0) {
-                    wl[wt.x] = make_int2(other, r);
-                    const int t = r ^ 1;
-                    const uint32_t pos = atomicAdd(&whdr[t].size, 1u);
-                    const MsWatchHdr th = whdr[t];
-                    if (pos < th.cap) pool[th.base + pos] = wt;
-                    else {
-                        uint32_t o = atomicAdd((uint32_t*)w.ov_cnt, 1u);
-                        int32_t* ov = WK_PTR(int32_t, w, L, overflow);
-                        ov[3 * o] = t;
-                        ov[3 * o + 1] = wt.x;
-                        ov[3 * o + 2] = other;
-                    }
-                    keep = false;
-                } else if (vo == MS_VAL_FALSE) cf = true;
-                else { want = true; imp = other; }
-            }
-            w.c_cl_lit += nl;
+            const int2 wt = act ? pool[wb + i] : make_int2(-1, 0);
+            const bool live = act && wt.x >= 0;
+            const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
+            const int2 ww = live ? wl[wt.x] : make_int2(0, 0);
+            const MsClauseHdr ch = live ? clause_hdr_of(w, sh, L, wt.x) : MsClauseHdr{0, 0};
             w.c_watch += (uint32_t)popc64(ballot(live));
-            w.c_move += (uint32_t)popc64(ballot(live && !keep));
-            // in-place compaction of the kept watchers of each group's list (dest <= source)
-            const u64 km = ballot(keep);
+            LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, ch, fl, g, bf);
+            w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
+            const u64 km = ballot(R.keep);
             wave_fence();
-            {   // a watcher that stays in place with its old blocker is not written back (saves a dirty line)
+            {
                 const int d = j + popc64(km & gmask & lanemask_lt(w.lane));
-                if (keep && (d != i || wt.y != blocker0)) pool[wb + d] = wt;
+                if (R.keep && (d != i || R.wt.y != wt.y)) pool[wb + d] = R.wt;
             }
             j += popc64(km & gmask);
             done = min(n, (it + 1) * S);
-            const u64 dm = ballot(deferred);
+            const u64 dm = ballot(R.deferred);
             if (dm) defer_g = min(defer_g, first_lane(dm) >> (6 - lg));
             repair_overflow(w, sh, L);
-            commit_implications<LV>(w, sh, L, want, imp, wt.x, lost);
-            const u64 cm = ballot(cf || lost);
+            commit_implications<LV>(w, sh, L, R.want, R.imp, wt.x, lost);
+            const u64 cm = ballot(R.cf || lost);
             if (cm) {
+                any_cf = true;
                 w.confl_kind = 1;
                 w.confl_cref = bcast(wt.x, first_lane(cm));
-                break;
             }
-            if (w.status != MS_ST_RUNNING) break;
         }
-        PROF_MARK(PF_LONG);
         // close each group's list: fully visited -> new size; interrupted -> tombstone the gap
         // between the compacted prefix and the first unvisited entry
         wave_fence();
         if (done == n) {
-            if (sl == 0 && n > 0) whdr[p].size = (uint32_t)j;
+            if (sl == 0 && n > 0 && j != n) whdr[p].size = (uint32_t)j;
         } else {
             for (int x = j + sl; x < done; x += S) pool[wb + x] = make_int2(-1, 0);
         }

@@ -19,7 +19,7 @@
 
 #define MS_WAVE 64
 #define MS_LDS_RING 256           // per-wave propagation queue window in LDS (entries)
-#define MS_CLAIM_SLOTS 128        // per-wave implication claim table in LDS
+#define MS_CLAIM_SLOTS 256        // per-wave implication claim set in LDS (<= 192 candidates per commit)
 #define MS_OVERFLOW_CAP 192       // watcher pushes that found their list full, per chunk
 #define MS_LBDQ 50                // Glucose restart window
 #define MS_MAX_GROUPS 16          // queue literals propagated per step (lane groups per wave)
@@ -45,7 +45,7 @@
 #define MS_TERN_REASON_ENTRY(r) (MS_TERN_BASE - (r))
 #define MS_IS_BIN_REASON(r) ((r) <= -2 && (r) > MS_TERN_BASE)
 #define MS_BIN_REASON_LIT(r) (-2 - (r))
-#define MS_MAX_VARS (1u << 27)
+#define MS_MAX_VARS (1u << 24)
 
 enum {
     MS_ST_RUNNING = 0,
