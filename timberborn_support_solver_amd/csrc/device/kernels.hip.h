@@ -1146,11 +1146,12 @@ struct LoopState {
 };
 
 // A conflict was found by propagate(): learn, backjump, assert (Glucose `search` conflict branch).
+// Returns true when a restart or a learnt-clause reduction is due at the next fixpoint.
 template <bool LV>
-DEV_COLD void on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls) {
+DEV_COLD bool on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls) {
     PROF_DECL
     ls.conflicts++;
-    if (w.n_levels == 0) { w.status = MS_ST_UNSAT; return; }
+    if (w.n_levels == 0) { w.status = MS_ST_UNSAT; return false; }
     // Glucose restart blocking: a trail much longer than its running average
     // (an exponential average stands in for the 5000-entry queue)
     ls.trail_avg += ((double)w.trail_n - ls.trail_avg) * (1.0 / 5000.0);
@@ -1159,16 +1160,16 @@ DEV_COLD void on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     }
     Learnt lr = analyze(w, sh, L);
     PROF_MARK(PF_ANALYZE);
-    if (w.status != MS_ST_RUNNING) return;
+    if (w.status != MS_ST_RUNNING) return false;
     const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
     cancel_until<LV>(w, sh, L, lr.bt_level);
     if (lr.n == 1) {
         int l0 = uni(learnt_buf[0]);  // unit learnt: bt_level is 0
-        if (lit_value<LV>(w, sh, L, l0) == MS_VAL_FALSE) { w.status = MS_ST_UNSAT; return; }
+        if (lit_value<LV>(w, sh, L, l0) == MS_VAL_FALSE) { w.status = MS_ST_UNSAT; return false; }
         enqueue_uniform<LV>(w, sh, L, l0, MS_REASON_NONE);
     } else {
         int cref = add_learnt<LV>(w, sh, L, lr.n, lr.lbd);
-        if (cref < 0) return;
+        if (cref < 0) return false;
         enqueue_uniform<LV>(w, sh, L, uni(learnt_buf[0]), cref);
     }
     PROF_MARK(PF_BACKJUMP);
@@ -1181,6 +1182,11 @@ DEV_COLD void on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     lds_fence();
     ls.lbdq_i = (ls.lbdq_i + 1) % MS_LBDQ;
     ls.lbd_total += lr.lbd;
+    const bool restart_due = ls.lbdq_n == MS_LBDQ &&
+                             ((double)ls.lbdq_sum / MS_LBDQ) * 0.8 > (double)ls.lbd_total / (double)ls.conflicts;
+    const bool reduce_due = ls.conflicts >= ls.next_reduce || w.n_learnts > L.learnt_cap - L.learnt_cap / 8 ||
+                            w.lc_lits_n > L.learnt_lit_cap - L.learnt_lit_cap / 8;
+    return restart_due || reduce_due;
 }
 
 // BCP reached a fixpoint without conflict: restart? reduce? then assumptions / next decision.
@@ -1253,6 +1259,7 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     ls.learnt_total = st->learnt_total; ls.learnt_lits_total = st->learnt_lits_total;
     ls.lbdq_n = st->lbdq_n; ls.lbdq_i = st->lbdq_i; ls.trail_avg = st->trail_avg;
     ls.n_assumps = st->n_assumps; ls.lbdq = s_lbdq;
+    const int n_assumps_reg = ls.n_assumps;
     MsShared sc = sh;     // private copies for the cold calls (their address is taken)
     MsLayout lc = L;
     uint32_t slice_confl = 0;
@@ -1264,11 +1271,12 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
         if (w.lane == 0) st->restart_req = 0;
     }
     const u64 tick0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
+    bool maintenance_due = true;   // first fixpoint of the slice goes through the full path once
     while (w.status == MS_ST_RUNNING) {
         if (prm.slice_ticks && __builtin_amdgcn_s_memrealtime() - tick0 >= prm.slice_ticks) break;
         if (propagate<LV>(w, sh, L)) {
             Wk t = w;
-            on_conflict<LV>(t, sc, lc, ls);
+            maintenance_due = on_conflict<LV>(t, sc, lc, ls);
             w = t;
             slice_confl++;
             if (slice_confl >= prm.slice_conflicts) break;
@@ -1279,9 +1287,21 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
         } else {
             if (w.status != MS_ST_RUNNING) break;
             if (prm.slice_props && w.c_props >= prm.slice_props) break;
-            Wk t = w;
-            on_fixpoint<LV>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc);
-            w = t;
+            if (maintenance_due || w.n_levels < n_assumps_reg || w.pool_top > L.pool_cap - L.pool_cap / 4) {
+                Wk t = w;   // restart / reduce / watch GC / assumptions: the full (cold) path
+                on_fixpoint<LV>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc);
+                w = t;
+                maintenance_due = false;
+            } else {        // common case: just the next decision
+                PROF_DECL
+                const int v = pick_branch_var<LV>(w, sh, L);
+                if (v < 0) { w.status = MS_ST_SAT; break; }
+                w.c_dec++;
+                const int next = uni(2 * v + (int)VREC[v].phase);
+                new_decision_level(w, sh, L);
+                enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);
+                PROF_MARK(PF_DECIDE);
+            }
         }
     }
     if (entered_running && w.lane == 0 && prm.any_done &&
