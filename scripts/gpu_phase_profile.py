@@ -7,13 +7,13 @@ from timberborn_support_solver_amd import *
 prof = ctypes.CDLL(os.path.join(ROOT, "timberborn_support_solver_amd", "libmi355sat_prof.so"))
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 46
-W = int(sys.argv[3]) if len(sys.argv) > 3 else 1280
-slc = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 3072
+slc = int(sys.argv[4]) if len(sys.argv) > 4 else 500   # slice length in ms
 grid = WorldGrid.rect(size, size)
 enc = Encoding.encode(PLATFORMS_DEFAULT, grid)
 cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
-for kw in (dict(max_groups=8, lds_val=1), dict(max_groups=1, lds_val=1)):
-    s = Mi355Sat(workers=W, slice_conflicts=slc, conflict_budget=W * slc, verbose=1, _lib_override=prof, **kw)
+for kw in (dict(),):
+    s = Mi355Sat(workers=W, slice_ms=slc, conflict_budget=1, verbose=1, _lib_override=prof, **kw)
     s.add_cnf(cnf.lits, cnf.offsets)
     t = time.time(); r = s.solve(); dt = time.time() - t
     st = s.stats()

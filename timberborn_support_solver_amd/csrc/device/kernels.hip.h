@@ -69,7 +69,7 @@ struct Wk {
     volatile int32_t* ring;
     volatile uint32_t* claim;
     volatile uint32_t* ov_cnt;
-    volatile uint32_t* hist;   // 64 words, reduce_db
+    volatile uint32_t* hist;   // 64 words, reduce_db; also the scratch of flat_setup (BCP)
     volatile uint32_t* lval;   // packed assignment, 2 bits per variable (LV variants)
     // hot uniform scalars
     int lane;
@@ -381,6 +381,33 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
     return R;
 }
 
+// Flat work distribution for the REMAINDER of long read-only lists: group g still has rem entries
+// (after its first S), described by two per-group words a, b.  Leaders publish (rem, a, b) in LDS,
+// lanes 0..15 scan, and afterwards lane `item` finds its (group, index) by walking the scan.  Returns
+// the total number of items.  w.hist layout: [0..16) rem, [16..32) a, [32..48) b, [48..64) inclusive scan.
+DEV int flat_setup(Wk& w, int G, int g, int sl, int rem, int a, int b) {
+    volatile uint32_t* fs = w.hist;
+    lds_fence();
+    if (sl == 0) { fs[g] = (uint32_t)rem; fs[16 + g] = (uint32_t)a; fs[32 + g] = (uint32_t)b; }
+    lds_fence();
+    int x = w.lane < G ? (int)fs[w.lane] : 0;
+    for (int o = 1; o < 16; o <<= 1) {
+        int t = __shfl_up(x, o, 64);
+        if (w.lane >= o) x += t;
+    }
+    if (w.lane < 16) fs[48 + w.lane] = (uint32_t)x;
+    lds_fence();
+    return (int)fs[48 + G - 1];
+}
+DEV void flat_item(const Wk& w, int G, int item, int& gg, int& idx, int& a, int& b) {
+    volatile uint32_t* fs = w.hist;
+    gg = 0;
+    while (gg < G - 1 && (int)fs[48 + gg] <= item) gg++;
+    idx = item - (gg ? (int)fs[48 + gg - 1] : 0);
+    a = (int)fs[16 + gg];
+    b = (int)fs[32 + gg];
+}
+
 // Unit propagation to fixpoint.  Returns true on conflict (w.confl_*).
 template <bool LV>
 DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
@@ -500,44 +527,61 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         }
         PROF_MARK(PF_TERN);
         bool lost;
-        // ---- remaining chunks of long binary lists -------------------------
-        for (uint32_t it = 1; !any_cf && ballot(it * S < nb) != 0; it++) {
-            const uint32_t i = it * S + (uint32_t)sl;
-            const bool act = i < nb;
-            const int q = act ? sh.bin_lits[b0 + i] : 0;
-            const int v = act ? lit_value<LV>(w, sh, L, q) : MS_VAL_TRUE;
-            w.c_watch += (uint32_t)popc64(ballot(act));
-            commit_implications<LV>(w, sh, L, v == MS_VAL_UNDEF, q, MS_REASON_BIN(fl), lost);
-            const u64 cm = ballot(v == MS_VAL_FALSE || lost);
-            if (cm) {
-                const int f = first_lane(cm);
-                any_cf = true;
-                w.confl_kind = 2;
-                w.confl_a = bcast(fl, f);
-                w.confl_b = bcast(q, f);
+        // ---- the rest of long binary lists, spread flat over all 64 lanes ----
+        {
+            const int rem = nb > (uint32_t)S ? (int)nb - S : 0;
+            if (!any_cf && ballot(rem > 0) != 0) {
+                const int total = flat_setup(w, G, g, sl, rem, (int)b0, fl);
+                for (int base = 0; !any_cf && base < total; base += MS_WAVE) {
+                    const int item = base + w.lane;
+                    const bool act = item < total;
+                    int gg = 0, i = 0, fb0 = 0, ffl = 0;
+                    if (act) flat_item(w, G, item, gg, i, fb0, ffl);
+                    const int q = act ? sh.bin_lits[(uint32_t)fb0 + (uint32_t)S + (uint32_t)i] : 0;
+                    const int v = act ? lit_value<LV>(w, sh, L, q) : MS_VAL_TRUE;
+                    w.c_watch += (uint32_t)popc64(ballot(act));
+                    commit_implications<LV>(w, sh, L, v == MS_VAL_UNDEF, q, MS_REASON_BIN(ffl), lost);
+                    const u64 cm = ballot(v == MS_VAL_FALSE || lost);
+                    if (cm) {
+                        const int f = first_lane(cm);
+                        any_cf = true;
+                        w.confl_kind = 2;
+                        w.confl_a = bcast(ffl, f);
+                        w.confl_b = bcast(q, f);
+                    }
+                }
             }
         }
-        // ---- remaining chunks of long ternary lists ------------------------
-        for (uint32_t it = 1; !any_cf && ballot(it * S < nt) != 0; it++) {
-            const uint32_t i = it * S + (uint32_t)sl;
-            const bool act = i < nt;
-            const int2 pr = act ? ((const int2*)sh.tern_pairs)[t0 + i] : make_int2(0, 0);
-            const int xb = act ? lit_value<LV>(w, sh, L, pr.x) : MS_VAL_TRUE;
-            const int xc = act ? lit_value<LV>(w, sh, L, pr.y) : MS_VAL_TRUE;
-            w.c_watch += (uint32_t)popc64(ballot(act));
-            const bool sat = xb == MS_VAL_TRUE || xc == MS_VAL_TRUE;
-            const bool cf = !sat && xb == MS_VAL_FALSE && xc == MS_VAL_FALSE;
-            const bool want = !sat && !cf && (xb == MS_VAL_FALSE || xc == MS_VAL_FALSE);
-            const int imp = xb == MS_VAL_FALSE ? pr.y : pr.x;
-            commit_implications<LV>(w, sh, L, want, imp, MS_REASON_TERN(t0 + i), lost);
-            const u64 cm = ballot(cf || lost);
-            if (cm) {
-                const int f = first_lane(cm);
-                any_cf = true;
-                w.confl_kind = 3;
-                w.confl_a = bcast(fl, f);
-                w.confl_b = bcast(pr.x, f);
-                w.confl_c = bcast(pr.y, f);
+        // ---- the rest of long ternary lists, likewise ----------------------
+        {
+            const int rem = nt > (uint32_t)S ? (int)nt - S : 0;
+            if (!any_cf && ballot(rem > 0) != 0) {
+                const int total = flat_setup(w, G, g, sl, rem, (int)t0, fl);
+                for (int base = 0; !any_cf && base < total; base += MS_WAVE) {
+                    const int item = base + w.lane;
+                    const bool act = item < total;
+                    int gg = 0, i = 0, ft0 = 0, ffl = 0;
+                    if (act) flat_item(w, G, item, gg, i, ft0, ffl);
+                    const uint32_t e = (uint32_t)ft0 + (uint32_t)S + (uint32_t)i;
+                    const int2 pr = act ? ((const int2*)sh.tern_pairs)[e] : make_int2(0, 0);
+                    const int xb = act ? lit_value<LV>(w, sh, L, pr.x) : MS_VAL_TRUE;
+                    const int xc = act ? lit_value<LV>(w, sh, L, pr.y) : MS_VAL_TRUE;
+                    w.c_watch += (uint32_t)popc64(ballot(act));
+                    const bool sat = xb == MS_VAL_TRUE || xc == MS_VAL_TRUE;
+                    const bool cf = !sat && xb == MS_VAL_FALSE && xc == MS_VAL_FALSE;
+                    const bool want = !sat && !cf && (xb == MS_VAL_FALSE || xc == MS_VAL_FALSE);
+                    const int imp = xb == MS_VAL_FALSE ? pr.y : pr.x;
+                    commit_implications<LV>(w, sh, L, want, imp, MS_REASON_TERN(e), lost);
+                    const u64 cm = ballot(cf || lost);
+                    if (cm) {
+                        const int f = first_lane(cm);
+                        any_cf = true;
+                        w.confl_kind = 3;
+                        w.confl_a = bcast(ffl, f);
+                        w.confl_b = bcast(pr.x, f);
+                        w.confl_c = bcast(pr.y, f);
+                    }
+                }
             }
         }
         // ---- remaining chunks of the watch lists ----------------------------
@@ -1334,13 +1378,14 @@ template <bool LV>
 __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
+    __shared__ uint32_t s_hist[64];
     __shared__ uint32_t s_ov;
     HIP_DYNAMIC_SHARED(uint32_t, s_lval)
     const uint32_t wid = blockIdx.x;
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = nullptr; w.lval = s_lval;
+    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval;
     if (w.lane == 0) s_ov = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     lds_fence();
