@@ -584,36 +584,43 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 }
             }
         }
-        // ---- remaining chunks of the watch lists ----------------------------
-        for (int it = 1; !any_cf && w.status == MS_ST_RUNNING && ballot(it * S < n) != 0; it++) {
-            const int i = it * S + sl;
-            const bool act = i < n;
-            const int2 wt = act ? pool[wb + i] : make_int2(-1, 0);
-            const bool live = act && wt.x >= 0;
-            const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
-            const int2 ww = live ? wl[wt.x] : make_int2(0, 0);
-            const MsClauseHdr ch = live ? clause_hdr_of(w, sh, L, wt.x) : MsClauseHdr{0, 0};
-            w.c_watch += (uint32_t)popc64(ballot(live));
-            LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, ch, fl, g, bf);
-            w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
-            const u64 km = ballot(R.keep);
-            wave_fence();
-            {
-                const int d = j + popc64(km & gmask & lanemask_lt(w.lane));
-                if (R.keep && (d != i || R.wt.y != wt.y)) pool[wb + d] = R.wt;
+        // ---- the rest of long watch lists: one list at a time, 64 watchers per iteration ----
+        for (u64 rm = ballot(n > S && sl == 0); rm != 0 && !any_cf && w.status == MS_ST_RUNNING; rm &= rm - 1) {
+            const int lf = first_lane(rm);                 // leader lane of the group that owns this list
+            const int gl = lf >> (6 - lg);
+            const int fl_l = bcast(fl, lf), n_l = bcast(n, lf);
+            const uint32_t wb_l = (uint32_t)bcast((int)wb, lf);
+            int j_l = bcast(j, lf), done_l = S;
+            for (int i0 = S; i0 < n_l && !any_cf && w.status == MS_ST_RUNNING; i0 += MS_WAVE) {
+                const int i = i0 + w.lane;
+                const bool act = i < n_l;
+                const int2 wt = act ? pool[wb_l + i] : make_int2(-1, 0);
+                const bool live = act && wt.x >= 0;
+                const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
+                const int2 ww = live ? wl[wt.x] : make_int2(0, 0);
+                const MsClauseHdr ch = live ? clause_hdr_of(w, sh, L, wt.x) : MsClauseHdr{0, 0};
+                w.c_watch += (uint32_t)popc64(ballot(live));
+                LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, ch, fl_l, gl, bf);
+                w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
+                const u64 km = ballot(R.keep);
+                wave_fence();
+                {
+                    const int d = j_l + popc64(km & lanemask_lt(w.lane));
+                    if (R.keep && (d != i || R.wt.y != wt.y)) pool[wb_l + d] = R.wt;
+                }
+                j_l += popc64(km);
+                done_l = min(n_l, i0 + MS_WAVE);
+                if (ballot(R.deferred)) defer_g = min(defer_g, gl);
+                repair_overflow(w, sh, L);
+                commit_implications<LV>(w, sh, L, R.want, R.imp, wt.x, lost);
+                const u64 cm = ballot(R.cf || lost);
+                if (cm) {
+                    any_cf = true;
+                    w.confl_kind = 1;
+                    w.confl_cref = bcast(wt.x, first_lane(cm));
+                }
             }
-            j += popc64(km & gmask);
-            done = min(n, (it + 1) * S);
-            const u64 dm = ballot(R.deferred);
-            if (dm) defer_g = min(defer_g, first_lane(dm) >> (6 - lg));
-            repair_overflow(w, sh, L);
-            commit_implications<LV>(w, sh, L, R.want, R.imp, wt.x, lost);
-            const u64 cm = ballot(R.cf || lost);
-            if (cm) {
-                any_cf = true;
-                w.confl_kind = 1;
-                w.confl_cref = bcast(wt.x, first_lane(cm));
-            }
+            if (g == gl) { j = j_l; done = done_l; }
         }
         // close each group's list: fully visited -> new size; interrupted -> tombstone the gap
         // between the compacted prefix and the first unvisited entry
