@@ -71,6 +71,7 @@ struct Wk {
     volatile uint32_t* ov_cnt;
     volatile uint32_t* hist;   // 64 words, reduce_db; also the scratch of flat_setup (BCP)
     volatile uint32_t* lval;   // packed assignment, 2 bits per variable (LV variants)
+    volatile int32_t* bfl;     // the false literal of each lane group of the current BCP step
     // hot uniform scalars
     int lane;
     int trail_n, qhead, n_levels, ring_lo;
@@ -300,7 +301,7 @@ DEV MsClauseHdr clause_hdr_of(const Wk& w, const MsShared& sh, const MsLayout& L
 // called by all 64 lanes (phase B is wave-cooperative).
 template <bool LV>
 DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, bool live, int vbl, int2 ww, MsClauseHdr ch,
-                      int fl, int g, const int (&bf)[MS_MAX_GROUPS]) {
+                      int fl, int g) {
     LongRes R;
     R.wt = wt; R.live = live; R.keep = live; R.want = false; R.cf = false; R.deferred = false; R.imp = 0;
     bool scanning = false, need_tail = false;
@@ -324,10 +325,8 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
             // both watches false and the other one is being propagated by another group in
             // this very step: the lower group handles the clause, the higher one re-queues
             bool other_lower = false;
-            if (vo == MS_VAL_FALSE) {
-#pragma unroll
-                for (int gg = 0; gg < MS_MAX_GROUPS; gg++) other_lower = other_lower || (gg < g && bf[gg] == other);
-            }
+            if (vo == MS_VAL_FALSE)
+                for (int gg = 0; gg < g; gg++) other_lower = other_lower || w.bfl[gg] == other;
             if (other_lower) R.deferred = true;
             else {
                 R.wt.y = other;
@@ -420,6 +419,9 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
     int pf_idx = -1, pf_p = 0;
     MsLitHdr pf_lh = {0, 0, 0, 0};
     MsWatchHdr pf_wh = {0, 0, 0, 0};
+    // ... and the first chunk of its three lists, issued together with this step's value snapshot
+    int pf_q0 = 0;
+    int2 pf_pr0 = make_int2(0, 0), pf_wt0 = make_int2(-1, 0);
     while (w.qhead < w.trail_n && w.status == MS_ST_RUNNING) {
         PROF_DECL
         // ---- split the wave into G groups of S lanes, one queue literal per group
@@ -434,7 +436,8 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         int p;
         MsLitHdr lh;
         MsWatchHdr wh;
-        if (idx == pf_idx) { p = pf_p; lh = pf_lh; wh = pf_wh; }
+        const bool hit = idx == pf_idx;
+        if (hit) { p = pf_p; lh = pf_lh; wh = pf_wh; }
         else {
             p = (idx >= w.ring_lo) ? w.ring[idx & (MS_LDS_RING - 1)] : trail[idx];
             lh = sh.lit_hdr[p];
@@ -444,11 +447,11 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const uint32_t b0 = lh.bin_off, nb = lh.bin_n, t0 = lh.tern_off, nt = lh.tern_n;
         const uint32_t wb = wh.base;
         const int n = (int)wh.size;
-        // round trip 1: the first chunk of all three lists
+        // round trip 1: the first chunk of all three lists (already here if the prefetch hit)
         const bool act_b = (uint32_t)sl < nb, act_t = (uint32_t)sl < nt;
-        const int q0 = act_b ? sh.bin_lits[b0 + sl] : 0;
-        const int2 pr0 = act_t ? ((const int2*)sh.tern_pairs)[t0 + sl] : make_int2(0, 0);
-        const int2 wt0 = sl < n ? pool[wb + sl] : make_int2(-1, 0);
+        const int q0 = hit ? pf_q0 : (act_b ? sh.bin_lits[b0 + sl] : 0);
+        const int2 pr0 = hit ? pf_pr0 : (act_t ? ((const int2*)sh.tern_pairs)[t0 + sl] : make_int2(0, 0));
+        const int2 wt0 = hit ? pf_wt0 : (sl < n ? pool[wb + sl] : make_int2(-1, 0));
         {   // prefetch the headers the next step will most likely use (same split, next G queue literals)
             const int nidx = qbase + G + g;
             pf_idx = -1;
@@ -462,10 +465,9 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         w.qhead += G;
         w.c_props += (uint32_t)G;
         w.c_steps++;
-        // the false literals of all groups of this step (uniform registers), for the clash test
-        int bf[MS_MAX_GROUPS];
-#pragma unroll
-        for (int gg = 0; gg < MS_MAX_GROUPS; gg++) bf[gg] = gg < G ? __shfl(fl, gg * S, 64) : -1;
+        // the false literals of all groups of this step (LDS), for the clash test in long_eval
+        if (sl == 0) w.bfl[g] = fl;
+        lds_fence();
         // round trip 2: ONE snapshot of every value the first chunks need, plus (speculatively) the
         // watched pair and the header of every live watcher's clause
         const bool live0 = sl < n && wt0.x >= 0;
@@ -475,6 +477,11 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
         const int2 ww0 = live0 ? wl[wt0.x] : make_int2(0, 0);
         const MsClauseHdr ch0 = live0 ? clause_hdr_of(w, sh, L, wt0.x) : MsClauseHdr{0, 0};
+        if (pf_idx >= 0) {   // same batch: the next step's first chunks (its headers have arrived by now)
+            pf_q0 = (uint32_t)sl < pf_lh.bin_n ? sh.bin_lits[pf_lh.bin_off + sl] : 0;
+            pf_pr0 = (uint32_t)sl < pf_lh.tern_n ? ((const int2*)sh.tern_pairs)[pf_lh.tern_off + sl] : make_int2(0, 0);
+            pf_wt0 = (uint32_t)sl < pf_wh.size ? pool[pf_wh.base + sl] : make_int2(-1, 0);
+        }
         PROF_MARK(PF_OFF);
         // evaluate binary + ternary entries on the snapshot
         const bool cf_b = vq == MS_VAL_FALSE, want_b = vq == MS_VAL_UNDEF;
@@ -486,7 +493,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         PROF_MARK(PF_BIN);
         // first chunk of the watch lists (round trips 3..: other watch + clause literals, pushes)
         int j = 0, done = 0, defer_g = MS_MAX_GROUPS;
-        LongRes R0 = long_eval<LV>(w, sh, L, wt0, live0, vbl0, ww0, ch0, fl, g, bf);
+        LongRes R0 = long_eval<LV>(w, sh, L, wt0, live0, vbl0, ww0, ch0, fl, g);
         PROF_MARK(PF_LONG);
         // ONE commit for the whole first chunk: binary, ternary and watched-clause implications
         bool any_cf;
@@ -600,7 +607,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 const int2 ww = live ? wl[wt.x] : make_int2(0, 0);
                 const MsClauseHdr ch = live ? clause_hdr_of(w, sh, L, wt.x) : MsClauseHdr{0, 0};
                 w.c_watch += (uint32_t)popc64(ballot(live));
-                LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, ch, fl_l, gl, bf);
+                LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, ch, fl_l, gl);
                 w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
                 const u64 km = ballot(R.keep);
                 wave_fence();
@@ -1291,13 +1298,14 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
     __shared__ uint32_t s_hist[64];
     __shared__ uint32_t s_lbdq[64];
+    __shared__ int32_t s_bfl[MS_MAX_GROUPS];
     __shared__ uint32_t s_ov;
     HIP_DYNAMIC_SHARED(uint32_t, s_lval)
     const uint32_t wid = blockIdx.x;
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval;
+    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
     if (w.lane == 0) s_ov = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     MsState* st = WKA(MsState, state);
@@ -1386,13 +1394,14 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
     __shared__ uint32_t s_hist[64];
+    __shared__ int32_t s_bfl[MS_MAX_GROUPS];
     __shared__ uint32_t s_ov;
     HIP_DYNAMIC_SHARED(uint32_t, s_lval)
     const uint32_t wid = blockIdx.x;
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval;
+    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
     if (w.lane == 0) s_ov = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     lds_fence();
