@@ -165,8 +165,9 @@ void mi355sat_interrupt(mi355sat* s);
 /* --- SolveStats::stats ----------------------------------------------------- */
 int mi355sat_stats(const mi355sat* s, mi355sat_stats_t* out);
 
-/* Optional DRUP-style log of learnt clauses of worker 0 (debug / UNSAT checking on
- * small instances).  Must be called before solve().  path NULL disables. */
+/* Optional DRUP proof (text, DIMACS literals, one learnt clause per line in derivation order, the
+ * empty clause last) of the next plain solve().  Logging makes that solve use ONE worker (a proof is
+ * the derivation of one search).  Must be called before solve(); path NULL disables. */
 int mi355sat_set_proof_path(mi355sat* s, const char* path);
 
 #ifdef __cplusplus

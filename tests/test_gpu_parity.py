@@ -152,6 +152,24 @@ def test_cube_splitting_mode_gives_the_same_verdicts():
         s.close()
 
 
+@pytest.mark.parametrize("terrain,pset,k", [("ex3", "1x1", 3), ("rect8x8", "default", 1), ("rect16x16", "default", 3),
+                                             ("rect16x16", "1x1", 10)])
+def test_unsat_verdicts_carry_a_checked_drup_proof(tmp_path, terrain, pset, k):
+    """UNSAT parity beyond agreement of solvers: the GPU's own derivation (DRUP log of its learnt
+    clauses) is verified by the oracle's forward RUP checker."""
+    from timberborn_support_solver_amd.dimacs import read_drup
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+    proof = str(tmp_path / "p.drup")
+    s = Mi355Sat()
+    s.set_proof_path(proof)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    assert s.solve() == SolverResult.Unsat
+    s.close()
+    assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof)) == 1
+
+
 def test_interrupt_and_budget():
     grid = make_grid("rect16x16")
     enc = Encoding.encode(platform_defs("1x1"), grid)

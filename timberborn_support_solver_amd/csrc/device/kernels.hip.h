@@ -1201,6 +1201,9 @@ struct LoopState {
     double trail_avg;
     int n_assumps;
     volatile uint32_t* lbdq;   // LDS ring of the last MS_LBDQ learnt-clause LBDs
+    int32_t* proof_buf;        // DRUP log (worker 0 only) or nullptr
+    uint32_t* proof_len;
+    uint32_t proof_cap;
 };
 
 // A conflict was found by propagate(): learn, backjump, assert (Glucose `search` conflict branch).
@@ -1220,6 +1223,16 @@ DEV_COLD bool on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     PROF_MARK(PF_ANALYZE);
     if (w.status != MS_ST_RUNNING) return false;
     const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
+    if (ls.proof_buf) {   // DRUP: every learnt clause, in derivation order
+        const uint32_t o = *ls.proof_len;
+        if (o + (uint32_t)lr.n + 1 <= ls.proof_cap) {
+            for (int i = w.lane; i < lr.n; i += MS_WAVE) ls.proof_buf[o + i] = learnt_buf[i];
+            if (w.lane == 0) ls.proof_buf[o + lr.n] = -1;
+        }
+        wave_fence();
+        if (w.lane == 0) *ls.proof_len = o + (uint32_t)lr.n + 1;
+        wave_fence();
+    }
     cancel_until<LV>(w, sh, L, lr.bt_level);
     if (lr.n == 1) {
         int l0 = uni(learnt_buf[0]);  // unit learnt: bt_level is 0
@@ -1318,6 +1331,7 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     ls.learnt_total = st->learnt_total; ls.learnt_lits_total = st->learnt_lits_total;
     ls.lbdq_n = st->lbdq_n; ls.lbdq_i = st->lbdq_i; ls.trail_avg = st->trail_avg;
     ls.n_assumps = st->n_assumps; ls.lbdq = s_lbdq;
+    ls.proof_buf = wid == 0 ? prm.proof_buf : nullptr; ls.proof_len = prm.proof_len; ls.proof_cap = prm.proof_cap;
     const int n_assumps_reg = ls.n_assumps;
     MsShared sc = sh;     // private copies for the cold calls (their address is taken)
     MsLayout lc = L;

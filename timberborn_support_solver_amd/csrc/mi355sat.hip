@@ -185,7 +185,8 @@ struct mi355sat {
     uint32_t lds_val_bytes = 0;
     DevBuf<char> d_template, d_slabs;
     DevBuf<MsState> d_states;
-    DevBuf<int32_t> d_any_done, d_assump, d_script;
+    DevBuf<int32_t> d_any_done, d_assump, d_script, d_proof;
+    DevBuf<uint32_t> d_proof_len;
     DevBuf<uint64_t> d_assump_off, d_script_off;
     MsShared sh{};
     MsLayout L{};
@@ -575,6 +576,9 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     prm.max_groups = s.opts.max_groups > 0 ? s.opts.max_groups : MS_MAX_GROUPS;
     prm.any_done = s.d_any_done.p;
     prm.done_on_refuted = done_on_refuted ? 1 : 0;
+    prm.proof_buf = s.d_proof.p;
+    prm.proof_len = s.d_proof_len.p;
+    prm.proof_cap = (uint32_t)s.d_proof.n;
     prm.reduce_first = s.opts.reduce_first > 0 ? (uint32_t)s.opts.reduce_first : 2000u;
     prm.reduce_inc = s.opts.reduce_inc > 0 ? (uint32_t)s.opts.reduce_inc : 300u;
     const uint32_t dyn = s.lds_val ? s.lds_val_bytes : 0;
@@ -594,6 +598,23 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     s.stats.kernel_seconds += ms * 1e-3;
     s.stats.kernel_launches++;
     return SliceResult{ms};
+}
+
+// DRUP text: one learnt clause per line in derivation order (DIMACS literals), then the empty clause.
+void write_proof(mi355sat& s, bool unsat) {
+    FILE* f = fopen(s.proof_path.c_str(), "w");
+    if (!f) throw HipErr{"cannot open proof file " + s.proof_path};
+    uint32_t n = 0;
+    if (s.d_proof_len.p) HIPCHK(hipMemcpy(&n, s.d_proof_len.p, sizeof n, hipMemcpyDeviceToHost));
+    if (n > s.d_proof.n) { fclose(f); throw HipErr{"proof buffer overflow (derivation too long to log)"}; }
+    std::vector<int32_t> buf(n);
+    if (n) HIPCHK(hipMemcpy(buf.data(), s.d_proof.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) {
+        if (buf[i] < 0) fputs("0\n", f);
+        else fprintf(f, "%d ", (buf[i] & 1) ? -((buf[i] >> 1) + 1) : ((buf[i] >> 1) + 1));
+    }
+    if (unsat) fputs("0\n", f);
+    fclose(f);
 }
 
 const char* status_text(int st) {
@@ -644,8 +665,17 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
         return 0;
     }
     uint32_t want = s.opts.workers > 0 ? (uint32_t)s.opts.workers : (s.offs.size() > 100000 ? 3072u : 256u);
+    if (!s.proof_path.empty()) want = 1;   // a DRUP proof is the derivation of ONE search: worker 0 alone
     if (want < n_instances) want = n_instances;
     want = want / n_instances * n_instances;
+    s.d_proof.release();
+    s.d_proof_len.release();
+    if (!s.proof_path.empty()) {
+        if (n_instances != 1) throw HipErr{"a proof can only be logged for a plain solve()"};
+        s.d_proof.alloc((size_t)64 << 20);
+        s.d_proof_len.alloc(1);
+        HIPCHK(hipMemsetAsync(s.d_proof_len.p, 0, sizeof(uint32_t), s.stream));
+    }
     sw.split = s.opts.cube_split > 0 && want > n_instances;   // opt-in: see DESIGN.md (measured: not yet a win)
     std::vector<int32_t> a_int(assump.size());
     for (size_t i = 0; i < assump.size(); i++) {
@@ -884,6 +914,7 @@ void mi355sat_free(mi355sat* s) {
     s->d_cl_hdr.release(); s->d_lit_hdr.release(); s->d_cl_lits.release(); s->d_bin_lits.release();
     s->d_tern_pairs.release(); s->d_tern_owner.release();
     s->d_template.release(); s->d_slabs.release(); s->d_states.release(); s->d_any_done.release();
+    s->d_proof.release(); s->d_proof_len.release();
     s->d_assump.release(); s->d_script.release(); s->d_assump_off.release(); s->d_script_off.release();
     if (s->stop_flag) (void)hipHostFree(s->stop_flag);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -962,6 +993,7 @@ int mi355sat_solve(mi355sat* s) {
         int rc = run_search(*s, assump, aoff, 1, results, winner, true);
         if (rc) { s->stats.solve_seconds += now_s() - t0; return rc; }
         result = results[0];
+        if (!s->proof_path.empty()) write_proof(*s, result == MI355SAT_UNSAT);
         s->model.clear();
         if (result == MI355SAT_SAT) fetch_model(*s, (uint32_t)winner[0], s->model, s->max_var);
     } catch (HipErr& he) {

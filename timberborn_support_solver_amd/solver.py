@@ -208,6 +208,10 @@ class Mi355Sat:
                                                      n_vars, _p(confl), _p(tl), repeat), "propagate_batch")
         return confl, vals, tl
 
+    def set_proof_path(self, path):
+        """DRUP proof of the next solve() (forces a single worker)."""
+        self._check(self._L.mi355sat_set_proof_path(self._h, path.encode() if path else None), "set_proof_path")
+
     def lit_val(self, lit):
         return self._L.mi355sat_val(self._h, int(lit))
 
