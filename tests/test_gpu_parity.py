@@ -170,6 +170,31 @@ def test_unsat_verdicts_carry_a_checked_drup_proof(tmp_path, terrain, pset, k):
     assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof)) == 1
 
 
+def test_cpp_solver_loop_cli_prints_the_reference_messages():
+    """The compiled host side (csrc/host/solver_loop.cpp + cli.cpp) over the C ABI: `rect 8 8 -l1:20`
+    is BASELINE.json configs[0] run on the GPU; ex3 from a project file is configs[3]."""
+    import os
+    import subprocess
+    from helpers import ROOT, terrain_rows
+    cli = os.path.join(ROOT, "timberborn_support_solver_amd", "tbs_cli")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "timberborn_support_solver_amd", "csrc"), "../tbs_cli"])
+    out = subprocess.run([cli, "rect", "8", "8", "-l1:20", "--workers", "64"], capture_output=True, text=True, timeout=120)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1] == "No solution found for the current constraints"
+    assert lines[0].startswith("Solution found (") and "Solution validation OK" in lines
+    assert "Solution validation FAILED" not in lines
+    assert [l for l in lines if l.startswith("Solution found")][-1] == "Solution found (2 platforms total)"   # k* = 2
+    toml = os.path.join(ROOT, "gpurun_out", "ex3_test.toml")
+    os.makedirs(os.path.dirname(toml), exist_ok=True)
+    with open(toml, "w") as f:
+        f.write("[world]\ngrid = [\n" + "".join(f'    "{r}",\n' for r in terrain_rows("ex3")) + "]\n")
+    out = subprocess.run([cli, "file", toml, "-l1:20", "--platforms", "1x1", "--workers", "64"], capture_output=True, text=True, timeout=120)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1] == "No solution found for the current constraints"
+    assert [l for l in lines if l.startswith("Solution found")][-1] == "Solution found (4 platforms total)"   # k* = 4 with 1x1 only
+
+
 def test_interrupt_and_budget():
     grid = make_grid("rect16x16")
     enc = Encoding.encode(platform_defs("1x1"), grid)
