@@ -128,7 +128,7 @@ def main():
     total_props, max_dt, total_confl = tot
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:   # reported baseline: rank 0 at N=1 only
         from oracle import oracle as ora
         o = ora.OracleSolver()
         o.add_cnf(cnf.lits, cnf.offsets)
