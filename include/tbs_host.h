@@ -56,6 +56,11 @@ tbs_cnf* tbs_encoding_base_cnf(const tbs_encoding* e);
  * assumptions -outputs[k'] on the same CNF. */
 tbs_cnf* tbs_with_limits_into_cnf(const tbs_encoding* e, const int64_t* limits_whk, int32_t n_limits,
                                   int32_t sweep);
+/* The same with platform weights and a bound on the total weight (the GUI's loop,
+ * crates/gui/src/app.rs:235-245): weights_whw = n_weights triples (w, h, weight >= 0). */
+tbs_cnf* tbs_with_limits_weights_into_cnf(const tbs_encoding* e, const int64_t* limits_whk, int32_t n_limits,
+                                          const int64_t* weights_whw, int32_t n_weights, int32_t has_weight_limit,
+                                          int64_t weight_limit, int32_t sweep);
 void tbs_cnf_free(tbs_cnf* c);
 uint32_t tbs_cnf_n_vars(const tbs_cnf* c);
 uint64_t tbs_cnf_n_clauses(const tbs_cnf* c);
@@ -74,6 +79,8 @@ int tbs_layout_platforms(const tbs_layout* l, int32_t* out5);
 /* counts[0..2] = unsupported terrain tiles, overlapping platforms, out-of-bounds platforms */
 int tbs_layout_validate(const tbs_layout* l, const uint8_t* cells, int32_t width, int32_t height,
                         int32_t counts[3]);
+/* PlatformLayout::total_weight (platform_layout.rs:174-183); weights_whw = n triples (w, h, weight) */
+int64_t tbs_layout_total_weight(const tbs_layout* l, const int64_t* weights_whw, int32_t n);
 int tbs_layout_trivial_optimization(tbs_layout* l, const uint8_t* cells, int32_t width, int32_t height);
 
 #ifdef __cplusplus

@@ -282,7 +282,80 @@ def totalizer_ub(clauses, n_vars, inputs, max_out):
     return build(0, len(inputs)), n_vars
 
 
-def into_cnf(clauses, n_vars, cards, keep_outputs=False):
+def gte_ub(clauses, n_vars, terms, bound):
+    """Generalized totalizer for sum(w*l) <= bound (published construction, Joshi et al. 2015; rustsat's own
+    is [ext]).  terms: [(lit, weight >= 0)].  Returns n_vars."""
+    kept, total = [], 0
+    for lit, wt in terms:
+        if wt < 0:
+            raise ValueError("negative weights are not supported")
+        if wt == 0:
+            continue
+        if wt > bound:
+            clauses.append([-lit])
+            continue
+        kept.append((lit, wt))
+        total += wt
+    if bound < 0:
+        clauses.append([])
+        return n_vars
+    if total <= bound or not kept:
+        return n_vars
+    cap = bound + 1
+
+    def build(lo, hi):
+        nonlocal n_vars
+        if hi - lo == 1:
+            return {kept[lo][1]: kept[lo][0]}
+        mid = lo + (hi - lo) // 2
+        a, b, r = build(lo, mid), build(mid, hi), {}
+
+        def out(w):
+            nonlocal n_vars
+            if w not in r:
+                n_vars += 1
+                r[w] = n_vars
+            return r[w]
+        for wa in sorted(a):
+            clauses.append([-a[wa], out(min(wa, cap))])
+        for wb in sorted(b):
+            clauses.append([-b[wb], out(min(wb, cap))])
+        for wa in sorted(a):
+            for wb in sorted(b):
+                clauses.append([-a[wa], -b[wb], out(min(wa + wb, cap))])
+        return r
+    root = build(0, len(kept))
+    if cap in root:
+        clauses.append([-root[cap]])
+    return n_vars
+
+
+def with_weights(enc, card_limits, weights, weight_limit):
+    """Encoding::with_limits including weights (encoder.rs:619-667): returns (clauses, n_vars, cards, pb_terms)."""
+    clauses = [list(c) for c in enc.clauses]
+    n_vars = enc.n_vars
+    cards, terms = [], []
+    for d in sorted(set(card_limits) | set(weights)):
+        if d[0] != d[1]:
+            lits = []
+            for y in range(enc.height):
+                for x in range(enc.width):
+                    n_vars += 1
+                    lits.append(n_vars)
+                    for dd in (d, (d[1], d[0])):
+                        v = enc.plat_var.get((x, y, dd))
+                        if v is not None:
+                            clauses.append([-v, n_vars])
+        else:
+            lits = [enc.plat_var[(x, y, d)] for y in range(enc.height) for x in range(enc.width)]
+        if d in card_limits:
+            cards.append((lits, card_limits[d]))
+        if weight_limit is not None and d in weights:
+            terms += [(l, weights[d]) for l in lits]
+    return clauses, n_vars, cards, terms
+
+
+def into_cnf(clauses, n_vars, cards, keep_outputs=False, pbs=()):
     """SatInstance::into_cnf restatement ([ext]); degenerate cases as SURVEY §8c(iii)."""
     clauses = [list(c) for c in clauses]
     outputs = []
@@ -299,4 +372,6 @@ def into_cnf(clauses, n_vars, cards, keep_outputs=False):
             outs, n_vars = totalizer_ub(clauses, n_vars, lits, k + 1)
             clauses.append([-outs[k]])
         outputs.append(outs)
+    for terms, bound in pbs:
+        n_vars = gte_ub(clauses, n_vars, terms, bound)
     return clauses, n_vars, outputs

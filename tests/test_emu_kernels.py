@@ -160,3 +160,23 @@ def test_emulated_unsat_verdicts_carry_a_drup_proof(tmp_path):
         write_dimacs(path, cnf.lits, cnf.offsets, cnf.n_vars)
         l2, o2, nv2 = read_dimacs(path)
         assert nv2 == cnf.n_vars and np.array_equal(l2, cnf.lits) and np.array_equal(o2, cnf.offsets)
+
+
+def test_emulated_weight_loop_like_the_gui():
+    """crates/gui/src/app.rs:235-245: tighten the total weight until Unsat; here with weights = platform area
+    on ex1 the loop must end at the minimum total area of a valid layout, every step validated."""
+    from timberborn_support_solver_amd import weight_loop
+    grid = make_grid("ex1")
+    defs = [(1, 1), (1, 2), (3, 3)]
+    enc = Encoding.encode(defs, grid)
+    weights = {(1, 1): 1, (1, 2): 1, (3, 3): 7}     # nested types add up: 1x2 = 1+1, 3x3 = 1+1+7 (platform_layout.rs:174-183)
+    hist = weight_loop(grid, enc, PlatformLimits({}, weights, None), make_solver=lambda: emu_solver(workers=1), out=lambda s: None)
+    assert hist[-1]["result"] == SolverResult.Unsat
+    ws = [h["weight"] for h in hist[:-1]]
+    assert all(h["valid"] for h in hist[:-1]) and ws == sorted(ws, reverse=True) and len(set(ws)) == len(ws)
+    assert hist[-1]["weight_limit"] == ws[-1] - 1
+    # the oracle agrees that one less is impossible
+    cnf = enc.with_limits_into_cnf(PlatformLimits({}, weights, ws[-1] - 1))
+    o = ora.OracleSolver()
+    o.add_cnf(cnf.lits, cnf.offsets)
+    assert o.solve() == 20

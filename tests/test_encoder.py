@@ -116,3 +116,39 @@ def test_sweep_outputs_pose_tighter_bounds_as_assumptions():
         s = ora.OracleSolver()
         s.add_cnf(cnf.lits, cnf.offsets)
         assert s.solve([-int(cnf.card_outputs[k])] if k < 8 else []) == want
+
+
+def test_weight_bound_matches_oracle_and_is_exactly_the_pb_constraint():
+    """with_limits with weights -> PbConstraint::new_ub -> generalized totalizer (encoder.rs:654-663)."""
+    from oracle import oracle as ora
+    grid = make_grid("rect5x4")
+    defs = [(1, 1), (1, 2), (2, 2)]
+    enc = Encoding.encode(defs, grid)
+    o = eo.Encoding(defs, eo.grid_from_rows(grid.rows()))
+    weights = {(1, 1): 2, (1, 2): 3, (2, 2): 5}
+    for wl in (0, 4, 7, 23, 10 ** 6):
+        cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 6}, weights, wl))
+        cl, nv, cards, terms = eo.with_weights(o, {(1, 1): 6}, weights, wl)
+        ocnf, onv, _ = eo.into_cnf(cl, nv, cards, pbs=[(terms, wl)])
+        assert cnf.clauses() == ocnf and cnf.n_vars == onv
+    # semantics by brute force on a tiny instance: extension exists iff weighted sum <= bound
+    grid = WorldGrid.rect(3, 1)
+    enc = Encoding.encode([(1, 1), (1, 2)], grid)
+    weights = {(1, 1): 2, (1, 2): 3}
+    base = enc.base_cnf().n_clauses
+    for wl in (0, 2, 4, 5, 9):
+        cnf = enc.with_limits_into_cnf(PlatformLimits({}, weights, wl))
+        extra = cnf.clauses()[base:]
+        p11 = [enc.platform_var(x, 0, (1, 1)) for x in range(3)]
+        # rectangular type: fresh per-tile "either orientation" vars are the first new variables
+        lim12 = list(range(enc.n_vars + 1, enc.n_vars + 4))
+        for bits in itertools.product([0, 1], repeat=6):
+            s = ora.OracleSolver()
+            units = [[v if b else -v] for v, b in zip(p11 + lim12, bits)]
+            lits, offs = ora.to_csr([c for c in extra if not (len(c) == 2 and c[1] in lim12 and -c[0] not in lim12)] + units)
+            s.reserve(cnf.n_vars)
+            s.add_cnf(lits, offs)
+            total = 2 * sum(bits[:3]) + 3 * sum(bits[3:])
+            assert (s.solve() == 10) == (total <= wl), (wl, bits)
+    with pytest.raises(EncoderError, match="negative"):
+        enc.with_limits_into_cnf(PlatformLimits({}, {(1, 1): -1}, 3))

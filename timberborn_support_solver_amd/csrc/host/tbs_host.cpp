@@ -112,6 +112,44 @@ std::vector<int32_t> totalizer_ub(Cnf& cnf, uint32_t& n_vars, const std::vector<
     return out;
 }
 
+// Generalized totalizer for sum(w_i * l_i) <= bound, w_i > 0 (the GUI's weight bound,
+// src/encoder.rs:654-663 -> rustsat PbConstraint -> GTE in into_cnf [ext]; restated from the
+// published construction: Joshi, Martins, Manquinho 2015).  Each node maps every reachable weight
+// sum (capped at bound+1) to an output variable; only the sum >= w => out_w direction is encoded.
+static void gte_ub(Cnf& cnf, uint32_t& n_vars, const std::vector<std::pair<int32_t, long>>& terms_in, long bound) {
+    std::vector<std::pair<int32_t, long>> terms;
+    long total = 0;
+    for (auto& t : terms_in) {
+        if (t.second < 0) throw std::runtime_error("into_cnf: negative platform weights are not supported");
+        if (t.second == 0) continue;
+        if (t.second > bound) { cnf.add({-t.first}); continue; }   // alone already over the bound
+        terms.push_back(t);
+        total += t.second;
+    }
+    if (bound < 0) { cnf.add(std::vector<int32_t>{}); return; }    // nothing can satisfy a negative bound
+    if (total <= bound || terms.empty()) return;
+    const long cap = bound + 1;
+    typedef std::map<long, int32_t> Node;
+    struct Rec {
+        Cnf& cnf; uint32_t& n_vars; const std::vector<std::pair<int32_t, long>>& t; long cap;
+        Node build(size_t lo, size_t hi) {
+            if (hi - lo == 1) return Node{{t[lo].second, t[lo].first}};
+            size_t mid = lo + (hi - lo) / 2;
+            Node a = build(lo, mid), b = build(mid, hi), r;
+            auto out = [&](long w) { auto it = r.find(w); if (it == r.end()) it = r.emplace(w, (int32_t)++n_vars).first; return it->second; };
+            for (auto& x : a) cnf.add({-x.second, out(std::min(x.first, cap))});
+            for (auto& y : b) cnf.add({-y.second, out(std::min(y.first, cap))});
+            for (auto& x : a)
+                for (auto& y : b) cnf.add({-x.second, -y.second, out(std::min(x.first + y.first, cap))});
+            return r;
+        }
+    } rec{cnf, n_vars, terms, cap};
+    Node root = rec.build(0, terms.size());
+    auto it = root.find(cap);
+    if (it != root.end()) cnf.add({-it->second});
+    if (n_vars > cnf.n_vars) cnf.n_vars = n_vars;
+}
+
 // SatInstance::into_cnf ([ext], called at crates/repl/src/main.rs:293 and
 // crates/gui/src/solver_backend.rs:78).  Degenerate bounds are simplified the way
 // SURVEY §8c (iii) records for rustsat: k >= n dropped, k == 0 -> n negative
@@ -137,8 +175,7 @@ Cnf SatInstance::into_cnf(std::vector<std::vector<int32_t>>* out_card_outputs) c
         }
         if (out_card_outputs) out_card_outputs->push_back(outs);
     }
-    if (!pbs.empty())
-        throw std::runtime_error("into_cnf: PB (weight) constraints are not implemented yet");
+    for (const PbUb& pb : pbs) gte_ub(out, nv, pb.terms, pb.bound);
     out.n_vars = std::max(out.n_vars, nv);
     return out;
 }

@@ -99,8 +99,21 @@ tbs_cnf* tbs_encoding_base_cnf(const tbs_encoding* e) {
 }
 
 tbs_cnf* tbs_with_limits_into_cnf(const tbs_encoding* e, const int64_t* lim, int32_t n_limits, int32_t sweep) {
+    return tbs_with_limits_weights_into_cnf(e, lim, n_limits, nullptr, 0, 0, 0, sweep);
+}
+
+tbs_cnf* tbs_with_limits_weights_into_cnf(const tbs_encoding* e, const int64_t* lim, int32_t n_limits, const int64_t* wts,
+                                          int32_t n_weights, int32_t has_weight_limit, int64_t weight_limit, int32_t sweep) {
     TBS_TRY
     PlatformLimits limits;
+    auto resolve = [&](Dims d) {   // dims -> platform def, crates/repl/src/main.rs:85-101
+        for (auto& p : e->enc.platform_defs())
+            if (p == d || p.flipped() == d) return p;
+        throw std::runtime_error("no platform with dimensions `" + std::to_string(d.w) + "x" + std::to_string(d.h) + "` found");
+    };
+    for (int i = 0; i < n_weights; i++) limits.weights[resolve(Dims{(int)wts[3 * i], (int)wts[3 * i + 1]})] = (long)wts[3 * i + 2];
+    limits.has_weight_limit = has_weight_limit != 0;
+    limits.weight_limit = (long)weight_limit;
     for (int i = 0; i < n_limits; i++) {
         Dims d{(int)lim[3 * i], (int)lim[3 * i + 1]};
         if (lim[3 * i + 2] < 0) throw std::runtime_error("expected non-negative integer");
@@ -169,6 +182,11 @@ int tbs_layout_validate(const tbs_layout* l, const uint8_t* cells, int32_t width
     counts[2] = (int32_t)r.out_of_bounds_platforms.size();
     return r.is_valid() ? 1 : 0;
     TBS_CATCH(-1)
+}
+int64_t tbs_layout_total_weight(const tbs_layout* l, const int64_t* wts, int32_t n) {
+    std::map<Dims, long> w;
+    for (int i = 0; i < n; i++) w[Dims{(int)wts[3 * i], (int)wts[3 * i + 1]}] = (long)wts[3 * i + 2];
+    return l->lay.total_weight(w);
 }
 int tbs_layout_trivial_optimization(tbs_layout* l, const uint8_t* cells, int32_t width, int32_t height) {
     TBS_TRY

@@ -50,6 +50,10 @@ def _H():
         L.tbs_encoding_base_cnf.argtypes = [vp]
         L.tbs_with_limits_into_cnf.restype = vp
         L.tbs_with_limits_into_cnf.argtypes = [vp, vp, i32, i32]
+        L.tbs_with_limits_weights_into_cnf.restype = vp
+        L.tbs_with_limits_weights_into_cnf.argtypes = [vp, vp, i32, vp, i32, i32, ctypes.c_int64, i32]
+        L.tbs_layout_total_weight.argtypes = [vp, vp, i32]
+        L.tbs_layout_total_weight.restype = ctypes.c_int64
         L.tbs_cnf_free.argtypes = [vp]
         L.tbs_cnf_n_vars.argtypes = [vp]
         L.tbs_cnf_n_vars.restype = ctypes.c_uint32
@@ -142,8 +146,10 @@ class Cnf:
 class PlatformLimits:
     """card_limits: {(w,h) platform def dims: max count} (platform_limits.rs:6-12)."""
 
-    def __init__(self, card_limits=None):
+    def __init__(self, card_limits=None, weights=None, weight_limit=None):
         self.card_limits = dict(card_limits or {})
+        self.weights = dict(weights or {})          # {(w,h): weight}   platform_limits.rs:10
+        self.weight_limit = weight_limit            # Option<isize>     platform_limits.rs:12
 
     @staticmethod
     def new_unweighted(limits):
@@ -211,7 +217,12 @@ class Encoding:
         Cnf.card_outputs so tighter bounds can be posed as assumptions."""
         items = sorted(limits.card_limits.items())
         arr = np.asarray([x for (d, k) in items for x in (d[0], d[1], k)], dtype=np.int64)
-        h = _H().tbs_with_limits_into_cnf(self._h, arr.ctypes.data if arr.size else None, len(items), 1 if sweep else 0)
+        witems = sorted(getattr(limits, "weights", {}).items())
+        warr = np.asarray([x for (d, wt) in witems for x in (d[0], d[1], wt)], dtype=np.int64)
+        wl = getattr(limits, "weight_limit", None)
+        h = _H().tbs_with_limits_weights_into_cnf(self._h, arr.ctypes.data if arr.size else None, len(items),
+                                                  warr.ctypes.data if warr.size else None, len(witems),
+                                                  0 if wl is None else 1, 0 if wl is None else int(wl), 1 if sweep else 0)
         if not h:
             raise EncoderError(_err())
         return Cnf(h)
@@ -262,6 +273,16 @@ class PlatformLayout:
         for (_, _, w, h, _) in self.platforms():
             stats[(w, h)] = stats.get((w, h), 0) + 1
         return stats
+
+    def total_weight(self, weights):
+        """platform_layout.rs:174-183: a platform counts the weight of every type contained in its definition dims."""
+        items = sorted(weights.items())
+        arr = np.asarray([x for (d, wt) in items for x in (d[0], d[1], wt)], dtype=np.int64)
+        return int(_H().tbs_layout_total_weight(self._h, arr.ctypes.data if arr.size else None, len(items)))
+
+    def run_trivial_optimization(self, grid):
+        cells = np.ascontiguousarray(grid.cells, dtype=np.uint8)
+        _H().tbs_layout_trivial_optimization(self._h, cells.ctypes.data, grid.width, grid.height)
 
     def validate(self, grid):
         counts = np.zeros(3, dtype=np.int32)

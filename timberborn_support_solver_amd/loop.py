@@ -64,3 +64,33 @@ def solver_loop(grid, encoding, limits, make_solver=None, out=print, on_interrup
         rec["valid"] = validation.is_valid()
         out("Solution validation OK" if rec["valid"] else "Solution validation FAILED")
     return history
+
+
+def weight_loop(grid, encoding, limits, make_solver=None, out=print, max_iterations=None):
+    """The GUI's weight-minimising loop (crates/gui/src/app.rs:148-175, 235-245): solve, take the layout
+    (after run_trivial_optimization), set weight_limit = total_weight - 1 and solve again until Unsat /
+    Interrupted or the weight cannot drop further.  Returns the per-iteration records."""
+    make_solver = make_solver or (lambda: Mi355Sat())
+    limits = PlatformLimits(dict(limits.card_limits), dict(limits.weights), limits.weight_limit)
+    history = []
+    while max_iterations is None or len(history) < max_iterations:
+        cnf = encoding.with_limits_into_cnf(limits)
+        solver = make_solver()
+        thunk, _ = run_solver(solver, cnf)
+        result, solver = thunk()
+        rec = {"weight_limit": limits.weight_limit, "result": result, "weight": None, "valid": None, "stats": solver.stats()}
+        history.append(rec)
+        if result != SolverResult.Sat:
+            out("No solution found for the current constraints" if result == SolverResult.Unsat else "Solver interrupted")
+            solver.close()
+            return history
+        layout = PlatformLayout.from_assignment(solver.full_solution(encoding.n_vars), encoding)
+        solver.close()
+        layout.run_trivial_optimization(grid)
+        weight = layout.total_weight(limits.weights)
+        rec.update(weight=weight, valid=layout.validate(grid).is_valid(), layout=layout)
+        out(f"Got a solution with weight {weight}")
+        if weight - 1 <= 0:
+            return history
+        limits.weight_limit = weight - 1
+    return history
