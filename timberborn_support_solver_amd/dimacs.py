@@ -34,7 +34,7 @@ def read_dimacs(path):
 
 
 def read_drup(path):
-    """DRUP text -> flat int32 array, clauses 0-terminated (what oracle.check_rup takes)."""
+    """DRUP text -> flat int32 array, clauses 0-terminated (the form a forward RUP checker takes)."""
     out = []
     with open(path) as f:
         for line in f:
