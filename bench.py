@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--size", type=int, default=64, help="rect SIZE x SIZE")
     ap.add_argument("--k-lo", type=int, default=44)
     ap.add_argument("--k-hi", type=int, default=51)
-    ap.add_argument("--workers", type=int, default=3072, help="wavefront workers per GPU (12 per CU)")
+    ap.add_argument("--workers", type=int, default=4096, help="wavefront workers per GPU (16 per CU)")
     ap.add_argument("--slice-ms", type=int, default=250, help="device time of one step (one kernel launch)")
     ap.add_argument("--cpu-conflicts", type=int, default=200000, help="conflict budget of the CPU baseline sample (~10-15 s)")
     ap.add_argument("--first-unsat-size", type=int, default=24, help="rect size of the wall-clock-to-first-UNSAT rung (0 = skip)")
@@ -159,7 +159,7 @@ def main():
         c2 = e2.with_limits_into_cnf(PlatformLimits({(1, 1): k0}), sweep=True)
         ks2 = list(range(k0, -1, -1))
         sets2 = [([-int(c2.card_outputs[k])] if k < k0 else []) for k in ks2]
-        sv = Mi355Sat(device=device_index, workers=max(len(ks2), 3072 // len(ks2) * len(ks2)), slice_ms=10)
+        sv = Mi355Sat(device=device_index, workers=max(len(ks2), 4096 // len(ks2) * len(ks2)), slice_ms=10)
         sv.add_cnf(c2.lits, c2.offsets)
         tg = time.perf_counter()
         sv.sweep_begin(sets2)

@@ -35,10 +35,10 @@
 
 typedef unsigned long long u64;
 
-// Register budget of the search kernel: 3 waves per SIMD = 12 workers per CU = 3072 per GPU
-// (measured: 4 per SIMD forces spills into the BCP loop and is slower in aggregate).
+// Register budget of the search kernel: 4 waves per SIMD = 16 workers per CU = 4096 per GPU.
+// (Measured on rect 64x64: 3.9e9 prop/s at 4/SIMD with ~50 spilled VGPRs vs 3.7e9 at 3/SIMD without spills.)
 #ifndef MS_SEARCH_WAVES_PER_SIMD
-#define MS_SEARCH_WAVES_PER_SIMD 3
+#define MS_SEARCH_WAVES_PER_SIMD 4
 #endif
 
 // Optional per-phase cycle stamps (diagnostic build only: make prof -> libmi355sat_prof.so).
@@ -415,13 +415,6 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
     int2* pool = WKA(int2, pool);
     const int2* wl = WKA(int2, wl);
     const int32_t* trail = WKA(int32_t, trail);
-    // headers prefetched for the NEXT step (queue literal index pf_idx), loaded while this step runs
-    int pf_idx = -1, pf_p = 0;
-    MsLitHdr pf_lh = {0, 0, 0, 0};
-    MsWatchHdr pf_wh = {0, 0, 0, 0};
-    // ... and the first chunk of its three lists, issued together with this step's value snapshot
-    int pf_q0 = 0;
-    int2 pf_pr0 = make_int2(0, 0), pf_wt0 = make_int2(-1, 0);
     while (w.qhead < w.trail_n && w.status == MS_ST_RUNNING) {
         PROF_DECL
         // ---- split the wave into G groups of S lanes, one queue literal per group
@@ -433,35 +426,18 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const u64 gmask = (S == MS_WAVE ? ~0ull : ((1ull << S) - 1ull)) << (g * S);
         const int qbase = w.qhead;
         const int idx = qbase + g;
-        int p;
-        MsLitHdr lh;
-        MsWatchHdr wh;
-        const bool hit = idx == pf_idx;
-        if (hit) { p = pf_p; lh = pf_lh; wh = pf_wh; }
-        else {
-            p = (idx >= w.ring_lo) ? w.ring[idx & (MS_LDS_RING - 1)] : trail[idx];
-            lh = sh.lit_hdr[p];
-            wh = whdr[p];
-        }
+        const int p = (idx >= w.ring_lo) ? w.ring[idx & (MS_LDS_RING - 1)] : trail[idx];
+        const MsLitHdr lh = sh.lit_hdr[p];
+        const MsWatchHdr wh = whdr[p];
         const int fl = p ^ 1;
         const uint32_t b0 = lh.bin_off, nb = lh.bin_n, t0 = lh.tern_off, nt = lh.tern_n;
         const uint32_t wb = wh.base;
         const int n = (int)wh.size;
-        // round trip 1: the first chunk of all three lists (already here if the prefetch hit)
+        // round trip 1: the first chunk of all three lists
         const bool act_b = (uint32_t)sl < nb, act_t = (uint32_t)sl < nt;
-        const int q0 = hit ? pf_q0 : (act_b ? sh.bin_lits[b0 + sl] : 0);
-        const int2 pr0 = hit ? pf_pr0 : (act_t ? ((const int2*)sh.tern_pairs)[t0 + sl] : make_int2(0, 0));
-        const int2 wt0 = hit ? pf_wt0 : (sl < n ? pool[wb + sl] : make_int2(-1, 0));
-        {   // prefetch the headers the next step will most likely use (same split, next G queue literals)
-            const int nidx = qbase + G + g;
-            pf_idx = -1;
-            if (nidx < w.trail_n) {
-                pf_idx = nidx;
-                pf_p = (nidx >= w.ring_lo) ? w.ring[nidx & (MS_LDS_RING - 1)] : trail[nidx];
-                pf_lh = sh.lit_hdr[pf_p];
-                pf_wh = whdr[pf_p];
-            }
-        }
+        const int q0 = act_b ? sh.bin_lits[b0 + sl] : 0;
+        const int2 pr0 = act_t ? ((const int2*)sh.tern_pairs)[t0 + sl] : make_int2(0, 0);
+        const int2 wt0 = sl < n ? pool[wb + sl] : make_int2(-1, 0);
         w.qhead += G;
         w.c_props += (uint32_t)G;
         w.c_steps++;
@@ -477,11 +453,6 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
         const int2 ww0 = live0 ? wl[wt0.x] : make_int2(0, 0);
         const MsClauseHdr ch0 = live0 ? clause_hdr_of(w, sh, L, wt0.x) : MsClauseHdr{0, 0};
-        if (pf_idx >= 0) {   // same batch: the next step's first chunks (its headers have arrived by now)
-            pf_q0 = (uint32_t)sl < pf_lh.bin_n ? sh.bin_lits[pf_lh.bin_off + sl] : 0;
-            pf_pr0 = (uint32_t)sl < pf_lh.tern_n ? ((const int2*)sh.tern_pairs)[pf_lh.tern_off + sl] : make_int2(0, 0);
-            pf_wt0 = (uint32_t)sl < pf_wh.size ? pool[pf_wh.base + sl] : make_int2(-1, 0);
-        }
         PROF_MARK(PF_OFF);
         // evaluate binary + ternary entries on the snapshot
         const bool cf_b = vq == MS_VAL_FALSE, want_b = vq == MS_VAL_UNDEF;
@@ -644,7 +615,6 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
             w.qhead = qbase + defer_g;
             w.c_props -= (uint32_t)(G - defer_g);
             w.c_redo += (uint32_t)(G - defer_g);
-            pf_idx = -1;
         }
     }
     return false;
@@ -703,21 +673,6 @@ DEV void vm_compact(Wk& w, const MsShared& sh, const MsLayout& L) {
     }
     w.vm_end = j;
     w.vm_search = j - 1;
-}
-
-// Cold-path calls: the callee works on private copies of the worker context and the
-// layout, so the hot loop's copy never has its address taken and stays in registers.
-#define WK_COPY_BACK(dst, src)                                                                        \
-    do {                                                                                              \
-        (dst).n_learnts = (src).n_learnts; (dst).lc_lits_n = (src).lc_lits_n; (dst).pool_top = (src).pool_top; \
-        (dst).status = (src).status; (dst).vm_end = (src).vm_end; (dst).vm_search = (src).vm_search;           \
-    } while (0)
-DEV void vm_compact_call(Wk& w, const MsShared& sh, const MsLayout& L) {
-    Wk t = w;
-    MsShared sc = sh;
-    MsLayout lc = L;
-    vm_compact(t, sc, lc);
-    WK_COPY_BACK(w, t);
 }
 
 template <bool LV>
@@ -929,15 +884,6 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
     return Learnt{n_out, bt, lbd};
 }
 
-DEV Learnt analyze_call(Wk& w, const MsShared& sh, const MsLayout& L) {
-    Wk t = w;
-    MsShared sc = sh;
-    MsLayout lc = L;
-    Learnt r = analyze(t, sc, lc);
-    w.status = t.status; w.vm_end = t.vm_end; w.vm_search = t.vm_search; w.lvl_stamp_ctr = t.lvl_stamp_ctr;
-    return r;
-}
-
 // ---- watch pool garbage collection ---------------------------------------------------
 // Lists that outgrow their slot are moved to the top of a bump pool and leave a
 // hole behind.  The rebuild lays every list out again, densely, straight from the
@@ -1094,22 +1040,6 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
         if (r >= 0 && (uint32_t)r >= sh.n_orig) VREC[v].reason = (int)(sh.n_orig + remap[(uint32_t)r - sh.n_orig]);
     }
     wave_fence();
-}
-
-template <bool LV>
-DEV void reduce_db_call(Wk& w, const MsShared& sh, const MsLayout& L) {
-    Wk t = w;
-    MsShared sc = sh;
-    MsLayout lc = L;
-    reduce_db<LV>(t, sc, lc);
-    WK_COPY_BACK(w, t);
-}
-DEV void rebuild_watches_call(Wk& w, const MsShared& sh, const MsLayout& L) {
-    Wk t = w;
-    MsShared sc = sh;
-    MsLayout lc = L;
-    rebuild_watches(t, sc, lc);
-    WK_COPY_BACK(w, t);
 }
 
 // Store the clause in learnt_buf[0..n) and attach it.  Returns its cref (or -1).

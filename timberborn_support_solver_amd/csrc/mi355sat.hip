@@ -664,7 +664,7 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
         s.trivially_unsat = true;
         return 0;
     }
-    uint32_t want = s.opts.workers > 0 ? (uint32_t)s.opts.workers : (s.offs.size() > 100000 ? 3072u : 256u);
+    uint32_t want = s.opts.workers > 0 ? (uint32_t)s.opts.workers : (s.offs.size() > 100000 ? MS_SEARCH_WAVES_PER_SIMD * 1024u : 256u);
     if (!s.proof_path.empty()) want = 1;   // a DRUP proof is the derivation of ONE search: worker 0 alone
     if (want < n_instances) want = n_instances;
     want = want / n_instances * n_instances;
