@@ -284,7 +284,9 @@ DEV void repair_overflow(Wk& w, const MsShared& sh, const MsLayout& L) {
 }
 
 // ---- one watcher of a long / learnt clause ---------------------------------------------
-#define MS_LANE_SCAN 8
+#ifndef MS_LANE_SCAN
+#define MS_LANE_SCAN 8   // clause literals the visiting lane examines itself (multiple of 4)
+#endif
 struct LongRes {
     int2 wt;            // watcher to keep (blocker possibly updated)
     bool live, keep, want, cf, deferred;
@@ -311,14 +313,16 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
     uint32_t nl = 0;
     if (live && vbl != MS_VAL_TRUE) {
         other = (ww.x == fl) ? ww.y : ww.x;
-        // the other watch and the first 8 literals: two 16-byte loads + their values, issued together
-        const int4 qa = *(const int4*)cl;
-        const int4 qb = size > 4 ? *(const int4*)(cl + 4) : make_int4(fl, fl, fl, fl);
-        vo = lit_value<LV>(w, sh, L, other);
-        const int ls[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        int vs[8];
+        // the other watch and the first MS_LANE_SCAN literals (16-byte loads) + their values, issued together
+        int ls[MS_LANE_SCAN], vs[MS_LANE_SCAN];
 #pragma unroll
-        for (int u = 0; u < 8; u++) vs[u] = (u < size && ls[u] != fl && ls[u] != other) ? lit_value<LV>(w, sh, L, ls[u]) : MS_VAL_FALSE;
+        for (int k = 0; k < MS_LANE_SCAN; k += 4) {
+            const int4 q = k < size ? *(const int4*)(cl + k) : make_int4(fl, fl, fl, fl);
+            ls[k] = q.x; ls[k + 1] = q.y; ls[k + 2] = q.z; ls[k + 3] = q.w;
+        }
+        vo = lit_value<LV>(w, sh, L, other);
+#pragma unroll
+        for (int u = 0; u < MS_LANE_SCAN; u++) vs[u] = (u < size && ls[u] != fl && ls[u] != other) ? lit_value<LV>(w, sh, L, ls[u]) : MS_VAL_FALSE;
         nl = 2;
         if (vo == MS_VAL_TRUE) R.wt.y = other;
         else {
@@ -332,7 +336,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
                 R.wt.y = other;
                 scanning = true;
 #pragma unroll
-                for (int u = 7; u >= 0; u--)
+                for (int u = MS_LANE_SCAN - 1; u >= 0; u--)
                     if (vs[u] != MS_VAL_FALSE) r = ls[u];
                 nl += (uint32_t)(size < MS_LANE_SCAN ? size : MS_LANE_SCAN);
                 need_tail = r < 0 && size > MS_LANE_SCAN;
@@ -1072,6 +1076,26 @@ DEV int add_learnt(Wk& w, const MsShared& sh, const MsLayout& L, int n, uint32_t
     return cref;
 }
 
+// Every field of Wk except `lane` and `c_cl_lit` has the same value in all lanes, but after a
+// vector load (HBM state, scratch copy of a cold call) the compiler cannot know that and would keep
+// ~35 VGPRs for them.  readfirstlane makes them scalar values again.
+DEV unsigned long long uni64(unsigned long long v) {
+    return ((unsigned long long)(uint32_t)uni((int)(v >> 32)) << 32) | (unsigned long long)(uint32_t)uni((int)v);
+}
+DEV void wk_uniformize(Wk& w) {
+    w.slab = (char*)uni64((unsigned long long)w.slab);
+    w.trail_n = uni(w.trail_n); w.qhead = uni(w.qhead); w.n_levels = uni(w.n_levels); w.ring_lo = uni(w.ring_lo);
+    w.vm_end = uni(w.vm_end); w.vm_search = uni(w.vm_search);
+    w.n_learnts = (uint32_t)uni((int)w.n_learnts); w.lc_lits_n = (uint32_t)uni((int)w.lc_lits_n);
+    w.pool_top = (uint32_t)uni((int)w.pool_top);
+    w.status = uni(w.status); w.lvl_stamp_ctr = (uint32_t)uni((int)w.lvl_stamp_ctr); w.max_groups = uni(w.max_groups);
+    w.confl_kind = uni(w.confl_kind); w.confl_cref = uni(w.confl_cref); w.confl_a = uni(w.confl_a);
+    w.confl_b = uni(w.confl_b); w.confl_c = uni(w.confl_c);
+    w.c_props = (uint32_t)uni((int)w.c_props); w.c_watch = (uint32_t)uni((int)w.c_watch);
+    w.c_move = (uint32_t)uni((int)w.c_move); w.c_enq = (uint32_t)uni((int)w.c_enq); w.c_dec = (uint32_t)uni((int)w.c_dec);
+    w.c_steps = (uint32_t)uni((int)w.c_steps); w.c_redo = (uint32_t)uni((int)w.c_redo);
+}
+
 // ---- worker load / store -------------------------------------------------------
 template <bool LV>
 DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const MsParams& prm) {
@@ -1251,6 +1275,7 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
     if (w.lane == 0) s_ov = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
+    wk_uniformize(w);
     MsState* st = WKA(MsState, state);
     if (w.lane < MS_LBDQ) s_lbdq[w.lane] = st->lbdq[w.lane];
     lds_fence();
@@ -1271,6 +1296,7 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
         Wk t = w;
         cancel_until<LV>(t, sc, lc, 0);
         w = t;
+        wk_uniformize(w);
         if (w.lane == 0) st->restart_req = 0;
     }
     const u64 tick0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
@@ -1281,6 +1307,7 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
             Wk t = w;
             maintenance_due = on_conflict<LV>(t, sc, lc, ls);
             w = t;
+            wk_uniformize(w);
             slice_confl++;
             if (slice_confl >= prm.slice_conflicts) break;
             if ((slice_confl & 63) == 0) {
@@ -1294,6 +1321,7 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
                 Wk t = w;   // restart / reduce / watch GC / assumptions: the full (cold) path
                 on_fixpoint<LV>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc);
                 w = t;
+                wk_uniformize(w);
                 maintenance_due = false;
             } else {        // common case: just the next decision
                 PROF_DECL
@@ -1348,6 +1376,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
     if (w.lane == 0) s_ov = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
+    wk_uniformize(w);
     lds_fence();
     const u64 t0 = __builtin_readcyclecounter();
     const int n_script = WKA(MsState, state)->n_script;
