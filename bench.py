@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--cpu-conflicts", type=int, default=200000, help="conflict budget of the CPU baseline sample (~10-15 s)")
     ap.add_argument("--first-unsat-size", type=int, default=24, help="rect size of the wall-clock-to-first-UNSAT rung (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--var-order", type=int, default=0, help="0 caller's numbering (default), 1 locality order (A/B)")
+    ap.add_argument("--share", type=int, default=0, help="0 learnt-clause exchange on (default), -1 off (A/B)")
     ap.add_argument("--platforms", default="default", choices=["default", "1x1"])
     args = ap.parse_args()
 
@@ -80,7 +82,8 @@ def main():
     assumption_sets = [([-int(outs[k])] if k < args.k_hi else []) for k in ks]
     workers = max(len(ks), args.workers // len(ks) * len(ks))
 
-    solver = Mi355Sat(device=device_index, workers=workers, slice_ms=args.slice_ms, seed=1000 + rank)
+    solver = Mi355Sat(device=device_index, workers=workers, slice_ms=args.slice_ms, seed=1000 + rank,
+                      var_order=args.var_order, share=args.share)
     solver.add_cnf(cnf.lits, cnf.offsets)
     solver.reserve(cnf.n_vars)
     solver.sweep_begin(assumption_sets)  # upload + replicate: everything resident in HBM from here on
@@ -171,6 +174,9 @@ def main():
             if sat_k is not None and unsat_k is not None and unsat_k + 1 >= sat_k:
                 kstar = sat_k
                 break
+            # implied by monotonicity: withdraw them, their workers join the open instances
+            sv.sweep_drop([i for i, k in enumerate(ks2) if res2[i] == SolverResult.Interrupted and
+                           ((sat_k is not None and k > sat_k) or (unsat_k is not None and k < unsat_k))])
         gpu_s = time.perf_counter() - tg
         sv.sweep_end()
         sv.close()

@@ -72,7 +72,19 @@ typedef struct mi355sat_opts {
     int32_t cube_split;        /* 0 (default): portfolio, every worker of an instance searches the whole instance with its
                                   own decision order; 1: idle workers steal sub-cubes of running ones between slices
                                   (correct but, as measured in round 1, slower: DESIGN.md) */
-    int32_t reserved[2];
+    int32_t share;             /* learnt-clause exchange between the workers of one GPU (units, binaries and clauses of
+                                  at most 7 literals with LBD <= share_lbd, passed on between kernel launches):
+                                  0 = default (on), -1 = off.  Off automatically with one worker or a proof log. */
+    int32_t share_lbd;         /* 0 = 2 */
+    int32_t share_interval;    /* > 0: a worker with unseen exchanged clauses restarts to attach them after this many of its
+                                  own conflicts; 0 = default: only at its own (Glucose) restarts - forced restarts measured
+                                  3-10x slower on the rect 24x24 ladder */
+    int32_t var_order;         /* 0 = default: the device keeps the caller's variable numbering; 1 = it renumbers variables so
+                                  that those meeting in clauses are neighbours (256-variable blobs grown breadth-first
+                                  through the clauses).  Invisible at this interface: literals, models and proofs are
+                                  always in the caller's numbering.  Measured on rect 64x64: no gain. */
+    int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
+                                  ones; -1 = they park */
 } mi355sat_opts;
 
 /* Counters.  n_deq .. n_enq are the five event counters of SURVEY.md §8(d)
@@ -96,7 +108,10 @@ typedef struct mi355sat_stats_t {
     uint64_t n_sat, n_unsat, n_terminated; /* rustsat SolverStats: results returned so far */
     uint64_t bcp_steps;        /* BCP steps; each propagates up to 16 queue literals (one per lane group) */
     uint64_t bcp_requeued;     /* literals re-queued because two groups met in one clause */
-    uint64_t reserved[6];
+    uint64_t shared_exported;  /* clauses workers offered to the exchange / clauses (and units) attached from it, */
+    uint64_t shared_imported;  /* summed over workers */
+    uint64_t shared_imported_units;
+    uint64_t reserved[3];
 } mi355sat_stats_t;
 
 /* --- lifecycle (Default::default / Drop) --------------------------------- */
@@ -134,6 +149,10 @@ int mi355sat_solve_batch(mi355sat* s, const int32_t* assumps, const uint64_t* as
  * end fetches the models of SAT instances (mi355sat_model_of) and drops the batch. */
 int mi355sat_sweep_begin(mi355sat* s, const int32_t* assumps, const uint64_t* assump_offsets, uint64_t n_instances);
 int mi355sat_sweep_step(mi355sat* s, int32_t* results /* may be NULL */, uint64_t* n_decided /* may be NULL */);
+/* Withdraw instances whose answer the caller no longer needs (in the decreasing-k sweep: every k above a
+ * SAT one and every k below an UNSAT one is implied).  Their result stays 0, they count as decided, and
+ * their workers move to the instances still open - as do the workers of every instance that gets its verdict. */
+int mi355sat_sweep_drop(mi355sat* s, const uint64_t* instances, uint64_t n);
 int mi355sat_sweep_end(mi355sat* s);
 
 /* Batched unit propagation (BCP only, no search): instance i enqueues its

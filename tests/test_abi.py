@@ -50,7 +50,7 @@ def test_product_sources_never_touch_the_oracle():
 
 def test_signature_and_opts_struct_layout():
     from timberborn_support_solver_amd.solver import Mi355SatOpts, Mi355SatStats
-    assert ctypes.sizeof(Mi355SatOpts) == 72
+    assert ctypes.sizeof(Mi355SatOpts) == 80
     assert ctypes.sizeof(Mi355SatStats) == 8 * (9 + 4 + 8 + 8)
     L = _lib.solver_lib()
     L.mi355sat_signature.restype = ctypes.c_char_p

@@ -180,3 +180,74 @@ def test_emulated_weight_loop_like_the_gui():
     o = ora.OracleSolver()
     o.add_cnf(cnf.lits, cnf.offsets)
     assert o.solve() == 20
+
+
+def test_emulated_clause_exchange_and_locality_order():
+    """Workers pass short / low-LBD learnt clauses on between slices (units are attached at level 0);
+    verdicts and models stay those of the formula, also with the device's own variable numbering."""
+    grid = make_grid("ex1")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 2}))                  # k* = 3: UNSAT
+    seen = 0
+    for kw in (dict(), dict(var_order=1), dict(share=-1)):
+        s = emu_solver(workers=8, slice_conflicts=8, **kw)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        assert s.solve() == SolverResult.Unsat
+        st = s.stats()
+        if kw.get("share") == -1:
+            assert st["shared_exported"] == 0 and st["shared_imported"] == 0
+        else:
+            assert st["shared_exported"] > 0
+            seen += st["shared_imported"] + st["shared_imported_units"]
+        s.close()
+    assert seen > 0
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 4}))
+    s = emu_solver(workers=8, slice_conflicts=8, var_order=1)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    assert s.solve() == SolverResult.Sat
+    check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, 4)
+    s.close()
+
+
+def test_emulated_locality_order_keeps_bcp_fixpoints_bit_exact():
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("default"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 6}))
+    scripts = [scripted_decisions(enc, grid, seed, 6) for seed in range(1, 5)] + [[]]
+    s = emu_solver(var_order=1)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    confl, vals, tl = s.propagate_batch(scripts, n_vars=cnf.n_vars)
+    for i, dec in enumerate(scripts):
+        c, v, n, _ = ora.bcp(cnf.lits, cnf.offsets, cnf.n_vars, dec)
+        assert c == confl[i]
+        if not c:
+            assert np.array_equal(v, vals[i]) and n == tl[i]
+    s.close()
+
+
+def test_emulated_sweep_moves_workers_to_open_instances_and_drops_implied_ones():
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 8}), sweep=True)
+    ks = [8, 6, 5, 4, 3, 2]                                                    # k* = 4
+    sets = [[-int(cnf.card_outputs[k])] if k < 8 else [] for k in ks]
+    s = emu_solver(workers=6, slice_conflicts=20)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    s.sweep_begin(sets)
+    for _ in range(400):
+        res, nd = s.sweep_step()
+        sat_k = min([k for k, r in zip(ks, res) if r == SolverResult.Sat], default=None)
+        unsat_k = max([k for k, r in zip(ks, res) if r == SolverResult.Unsat], default=None)
+        if sat_k is not None and unsat_k is not None and unsat_k + 1 >= sat_k:
+            break
+        s.sweep_drop([i for i, k in enumerate(ks) if res[i] == SolverResult.Interrupted and
+                      ((sat_k is not None and k > sat_k) or (unsat_k is not None and k < unsat_k))])
+    assert (sat_k, unsat_k) == (4, 3)
+    s.sweep_end()
+    i4 = ks.index(4)
+    check_sat_answer(cnf, s.solution_of(i4, cnf.n_vars), enc, grid, 4)
+    for i, k in enumerate(ks):                          # whatever else was decided is consistent with k* = 4
+        assert res[i] in (SolverResult.Interrupted, SolverResult.Sat if k >= 4 else SolverResult.Unsat)
+    s.close()

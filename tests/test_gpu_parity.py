@@ -229,3 +229,72 @@ def test_degenerate_inputs_on_device():
     m = s.full_solution(7)
     assert m[2] == -1 and (m[0] == 1) != (m[1] == 1) or (m[0] == 1 and m[1] == -1) or (m[0] == -1 and m[1] == 1)
     s.close()
+
+
+@pytest.mark.parametrize("kw", [dict(share=-1), dict(share=0, share_lbd=4), dict(var_order=1), dict(rebalance=-1)],
+                         ids=["no-exchange", "exchange-lbd4", "locality-order", "no-rebalance"])
+def test_exchange_order_and_rebalancing_never_change_an_answer(kw):
+    """The learnt-clause exchange, the device's own variable numbering and the migration of workers
+    are search strategy: verdicts equal the golden ones, models check against the caller's CNF."""
+    for terrain, pset, k, want in [("rect16x16", "default", 3, "UNSAT"), ("rect16x16", "default", 4, "SAT"),
+                                   ("ex2", "default", 3, "UNSAT"), ("rect8x8", "1x1", 3, "UNSAT")]:
+        grid = make_grid(terrain)
+        enc = Encoding.encode(platform_defs(pset), grid)
+        cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+        s = Mi355Sat(workers=256, slice_ms=2, **kw)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        r = s.solve()
+        assert r.name.upper() == want, (terrain, pset, k)
+        if r == SolverResult.Sat:
+            check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+        st = s.stats()
+        if kw.get("share") == -1:
+            assert st["shared_exported"] == 0 and st["shared_imported"] == 0
+        s.close()
+
+
+def test_locality_order_keeps_bcp_fixpoints_bit_exact():
+    grid = make_grid("rect16x16")
+    enc = Encoding.encode(platform_defs("default"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 40}))
+    scripts = [[]] + [scripted_decisions(enc, grid, seed, 12, p_positive=0.15) for seed in range(1, 9)]
+    s = Mi355Sat(var_order=1)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    confl, vals, tl = s.propagate_batch(scripts, n_vars=cnf.n_vars)
+    for i, dec in enumerate(scripts):
+        c, v, n, _ = ora.bcp(cnf.lits, cnf.offsets, cnf.n_vars, dec)
+        assert c == confl[i]
+        if not c:
+            assert n == tl[i] and np.array_equal(v, vals[i])
+    s.close()
+
+
+def test_sweep_with_exchange_migration_and_withdrawn_instances_finds_the_cut():
+    """The whole ladder as one batch (rect 16x16, k* = 4): workers of decided instances move to the open
+    ones, implied instances are withdrawn, exchanged clauses cross instance boundaries (they never
+    depend on assumptions).  The cut and its model must be the golden ones."""
+    grid = make_grid("rect16x16")
+    enc = Encoding.encode(platform_defs("default"), grid)
+    k0 = 10
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k0}), sweep=True)
+    ks = list(range(k0, -1, -1))
+    sets = [([-int(cnf.card_outputs[k])] if k < k0 else []) for k in ks]
+    s = Mi355Sat(workers=44 * len(ks), slice_ms=2)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    s.sweep_begin(sets)
+    t0 = time.time()
+    while time.time() - t0 < 60:
+        res, _ = s.sweep_step()
+        sat_k = min([k for k, r in zip(ks, res) if r == SolverResult.Sat], default=None)
+        unsat_k = max([k for k, r in zip(ks, res) if r == SolverResult.Unsat], default=None)
+        if sat_k is not None and unsat_k is not None and unsat_k + 1 >= sat_k:
+            break
+        s.sweep_drop([i for i, k in enumerate(ks) if res[i] == SolverResult.Interrupted and
+                      ((sat_k is not None and k > sat_k) or (unsat_k is not None and k < unsat_k))])
+    s.sweep_end()
+    assert (sat_k, unsat_k) == (4, 3)
+    check_sat_answer(cnf, s.solution_of(ks.index(4), cnf.n_vars), enc, grid, 4)
+    for k, r in zip(ks, res):
+        assert r in (SolverResult.Interrupted, SolverResult.Sat if k >= 4 else SolverResult.Unsat)
+    assert s.stats()["shared_exported"] > 0
+    s.close()

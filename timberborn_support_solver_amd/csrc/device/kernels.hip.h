@@ -1158,7 +1158,73 @@ struct LoopState {
     int32_t* proof_buf;        // DRUP log (worker 0 only) or nullptr
     uint32_t* proof_len;
     uint32_t proof_cap;
+    // clause exchange (share_pool == nullptr: off)
+    const int4* share_pool;
+    u64 share_n, share_pos, n_exported, n_imported, n_imported_units, last_import_confl;
+    uint32_t share_slots, share_max_lbd, share_interval, exp_n, wid;
 };
+
+// Attach the records of the global ring this worker has not seen yet.  Called at decision level 0
+// with the trail at its fixpoint.  Every record is a consequence of the formula alone (learnt clauses
+// never depend on assumptions: those are decisions), so it may be added to any worker of any instance
+// of the sweep.  A record that is a unit under the level-0 assignment is enqueued; the caller must run
+// BCP before its next decision when the queue is not empty afterwards.
+template <bool LV>
+DEV void import_shared(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls) {
+    u64 pos = ls.share_pos;
+    const u64 end = ls.share_n;
+    if (end - pos > ls.share_slots) pos = end - ls.share_slots;   // the ring overwrote what we never read
+    int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
+    int budget = 2048;   // records per call; the rest waits for the next restart
+    while (pos < end && budget > 0 && w.status == MS_ST_RUNNING) {
+        const u64 idx = pos + (u64)w.lane;
+        const bool have = idx < end;
+        int4 a = make_int4(0, 0, 0, 0), b = make_int4(0, 0, 0, 0);
+        if (have) {
+            const int4* r = ls.share_pool + (idx % ls.share_slots) * 2;
+            a = r[0];
+            b = r[1];
+        }
+        const int n = a.x & 15, lbd = (a.x >> 4) & 255;
+        bool act = have && n > 0 && (uint32_t)(a.x >> 12) != ls.wid;
+        if (act) {   // first look, one record per lane: most are already satisfied here
+            const int lits[MS_SHARE_MAXLEN] = {a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            bool sat = false;
+            for (int j = 0; j < MS_SHARE_MAXLEN; j++)
+                if (j < n && lit_value<LV>(w, sh, L, lits[j]) == MS_VAL_TRUE) sat = true;
+            act = !sat;
+        }
+        u64 m = ballot(act);
+        while (m && w.status == MS_ST_RUNNING) {
+            const int src = first_lane(m);
+            m &= m - 1;
+            const int rn = bcast(n, src), rl = bcast(lbd, src);
+            const int l0 = bcast(a.y, src), l1 = bcast(a.z, src), l2 = bcast(a.w, src), l3 = bcast(b.x, src),
+                      l4 = bcast(b.y, src), l5 = bcast(b.z, src), l6 = bcast(b.w, src);
+            const int mine = w.lane == 0 ? l0 : w.lane == 1 ? l1 : w.lane == 2 ? l2 : w.lane == 3 ? l3 : w.lane == 4 ? l4 : w.lane == 5 ? l5 : l6;
+            const bool in = w.lane < rn;
+            const int v = in ? lit_value<LV>(w, sh, L, mine) : MS_VAL_FALSE;   // units of this batch are visible
+            if (ballot(in && v == MS_VAL_TRUE)) continue;
+            const u64 free_m = ballot(in && v == MS_VAL_UNDEF);
+            const int cnt = popc64(free_m);
+            if (cnt == 0) { w.status = MS_ST_UNSAT; break; }        // falsified at level 0
+            if (cnt == 1) {
+                enqueue_uniform<LV>(w, sh, L, bcast(mine, first_lane(free_m)), MS_REASON_NONE);
+                ls.n_imported_units++;
+            } else {
+                if (w.n_learnts > L.learnt_cap / 2 && cnt > 2) continue;   // store half full: only binaries
+                if ((free_m >> w.lane) & 1) learnt_buf[popc64(free_m & lanemask_lt(w.lane))] = mine;
+                wave_fence();
+                // glue <= 2 would pin it for ever; an imported clause has to earn that here
+                if (add_learnt<LV>(w, sh, L, cnt, (uint32_t)(rl < 3 ? 3 : rl)) < 0) break;
+            }
+            ls.n_imported++;
+        }
+        pos += MS_WAVE;
+        budget -= MS_WAVE;
+    }
+    ls.share_pos = pos < end ? pos : end;
+}
 
 // A conflict was found by propagate(): learn, backjump, assert (Glucose `search` conflict branch).
 // Returns true when a restart or a learnt-clause reduction is due at the next fixpoint.
@@ -1187,6 +1253,14 @@ DEV_COLD bool on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         if (w.lane == 0) *ls.proof_len = o + (uint32_t)lr.n + 1;
         wave_fence();
     }
+    if (ls.share_pool && lr.n <= MS_SHARE_MAXLEN && (lr.n <= 2 || lr.lbd <= ls.share_max_lbd) && ls.exp_n < MS_EXPORT_RECS) {
+        int32_t* rec = WK_PTR(int32_t, w, L, exp) + ls.exp_n * MS_SHARE_REC;
+        if (w.lane < MS_SHARE_REC)
+            rec[w.lane] = w.lane == 0 ? (int)((uint32_t)lr.n | ((lr.lbd > 255u ? 255u : lr.lbd) << 4) | (ls.wid << 12))
+                                      : (w.lane <= lr.n ? learnt_buf[w.lane - 1] : 0);
+        ls.exp_n++;
+        ls.n_exported++;
+    }
     cancel_until<LV>(w, sh, L, lr.bt_level);
     if (lr.n == 1) {
         int l0 = uni(learnt_buf[0]);  // unit learnt: bt_level is 0
@@ -1211,7 +1285,8 @@ DEV_COLD bool on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
                              ((double)ls.lbdq_sum / MS_LBDQ) * 0.8 > (double)ls.lbd_total / (double)ls.conflicts;
     const bool reduce_due = ls.conflicts >= ls.next_reduce || w.n_learnts > L.learnt_cap - L.learnt_cap / 8 ||
                             w.lc_lits_n > L.learnt_lit_cap - L.learnt_lit_cap / 8;
-    return restart_due || reduce_due;
+    const bool import_due = ls.share_pool && ls.share_n > ls.share_pos && ls.conflicts - ls.last_import_confl >= ls.share_interval;
+    return restart_due || reduce_due || import_due;
 }
 
 // BCP reached a fixpoint without conflict: restart? reduce? then assumptions / next decision.
@@ -1233,6 +1308,13 @@ DEV_COLD void on_fixpoint(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     if (w.pool_top > L.pool_cap - L.pool_cap / 4) rebuild_watches(w, sh, L);  // pool running low: collect holes
     PROF_MARK(PF_REDUCE);
     if (w.status != MS_ST_RUNNING) return;
+    if (ls.share_pool && ls.share_n > ls.share_pos &&
+        (w.n_levels == 0 || ls.conflicts - ls.last_import_confl >= ls.share_interval)) {
+        if (w.n_levels > 0) cancel_until<LV>(w, sh, L, 0);   // other workers' clauses are waiting: take them at level 0
+        import_shared<LV>(w, sh, L, ls);
+        ls.last_import_confl = ls.conflicts;
+        if (w.status != MS_ST_RUNNING || w.qhead < w.trail_n) return;   // imported units: BCP first
+    }
     const int32_t* assumps = WK_PTR(int32_t, w, L, assumps);
     int next = -1;
     while (w.n_levels < ls.n_assumps) {
@@ -1287,6 +1369,12 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     ls.lbdq_n = st->lbdq_n; ls.lbdq_i = st->lbdq_i; ls.trail_avg = st->trail_avg;
     ls.n_assumps = st->n_assumps; ls.lbdq = s_lbdq;
     ls.proof_buf = wid == 0 ? prm.proof_buf : nullptr; ls.proof_len = prm.proof_len; ls.proof_cap = prm.proof_cap;
+    ls.share_pool = (const int4*)prm.share_pool;
+    ls.share_n = prm.share_pool ? *prm.share_n : 0;
+    ls.share_pos = st->share_pos; ls.n_exported = st->n_exported; ls.n_imported = st->n_imported;
+    ls.n_imported_units = st->n_imported_units; ls.last_import_confl = st->last_import_confl;
+    ls.share_slots = prm.share_slots; ls.share_max_lbd = prm.share_max_lbd; ls.share_interval = prm.share_interval;
+    ls.exp_n = st->exp_n; ls.wid = wid;
     const int n_assumps_reg = ls.n_assumps;
     MsShared sc = sh;     // private copies for the cold calls (their address is taken)
     MsLayout lc = L;
@@ -1353,6 +1441,9 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
         st->lbdq_sum = ls.lbdq_sum; st->lbd_total = ls.lbd_total; st->next_reduce = ls.next_reduce;
         st->lbdq_n = ls.lbdq_n; st->lbdq_i = ls.lbdq_i; st->trail_avg = ls.trail_avg;
         st->learnt_total = ls.learnt_total; st->learnt_lits_total = ls.learnt_lits_total;
+        st->share_pos = ls.share_pos; st->n_exported = ls.n_exported; st->n_imported = ls.n_imported;
+        st->n_imported_units = ls.n_imported_units; st->last_import_confl = ls.last_import_confl;
+        st->exp_n = ls.exp_n;
     }
     wk_store<LV>(w, sh, L, __builtin_readcyclecounter() - t0);
 }

@@ -24,6 +24,14 @@
 #define MS_LBDQ 50                // Glucose restart window
 #define MS_MAX_GROUPS 16          // queue literals propagated per step (lane groups per wave)
 #define MS_SPLIT_MAX 8            // decisions a worker offers per slice for splitting its cube
+// Learnt-clause exchange between the workers of one GPU: fixed 32-byte records
+//   word 0 = size | lbd << 4 | producer << 12,  words 1..7 = literals
+// A worker appends the short / low-LBD clauses it learns to its private export buffer; between two
+// slices ms_share_collect_kernel moves the new ones (deduplicated) into one global ring of records,
+// and every worker attaches the records it has not seen yet the next time it stands at level 0.
+#define MS_SHARE_REC 8            // int32 words per record
+#define MS_SHARE_MAXLEN 7         // longest clause that is exchanged
+#define MS_EXPORT_RECS 64         // per-worker export buffer (records per slice; more are dropped)
 
 // lit_value() results
 #define MS_VAL_TRUE 0
@@ -104,6 +112,7 @@ struct MsLayout {
     uint64_t overflow;    // int32  [3*MS_OVERFLOW_CAP]  (list, cref, blocker)
     uint64_t assumps;     // int32  [assump_cap]
     uint64_t script;      // int32  [script_cap]  decisions for propagate_batch
+    uint64_t exp;         // int32  [MS_EXPORT_RECS*MS_SHARE_REC]  clauses learnt in this slice that other workers get
     uint32_t n_vars, n_orig, learnt_cap, learnt_lit_cap, pool_cap, vm_cap, assump_cap, script_cap;
 };
 
@@ -119,7 +128,8 @@ struct MsState {
     // decision queue
     int32_t vm_end, vm_search;
     // learnt store
-    uint32_t n_learnts, lc_lits_n, pool_top, pad1;
+    uint32_t n_learnts, lc_lits_n, pool_top;
+    uint32_t exp_n;            // records in the export buffer
     // restarts (Glucose K=0.8 on LBD window, R=1.4 trail blocking)
     uint32_t lbdq[MS_LBDQ];
     uint32_t lbdq_n, lbdq_i;
@@ -136,7 +146,10 @@ struct MsState {
     uint64_t n_steps;          // BCP steps (each propagates up to MS_MAX_GROUPS literals)
     uint64_t n_redo;           // literals re-queued because two groups met in one clause
     uint64_t prof[10];         // per-phase cycle totals (profiling build only)
-    uint64_t reserved[2];
+    // clause exchange
+    uint64_t share_pos;        // records of the global ring this worker has looked at
+    uint64_t n_exported, n_imported, n_imported_units;
+    uint64_t last_import_confl;
 };
 
 // Launch parameters of one slice.
@@ -155,4 +168,11 @@ struct MsParams {
     int32_t* proof_buf;            // optional DRUP log of worker 0: learnt clauses as internal literals, -1 terminated
     uint32_t* proof_len;           // words used / wanted (the host detects overflow by proof_len > proof_cap)
     uint32_t proof_cap, pad2;
+    // clause exchange (share_pool == nullptr: off)
+    const int32_t* share_pool;     // ring of share_slots records
+    const unsigned long long* share_n;  // records ever appended (constant during a slice)
+    uint32_t share_slots;
+    uint32_t share_max_lbd;        // clauses with lbd <= this (or size <= 2) are exported
+    uint32_t share_interval;       // a worker with unseen records restarts to import them after this many conflicts
+    uint32_t pad3;
 };

@@ -132,6 +132,51 @@ __global__ void ms_gather_states_kernel(MsLayout L, const char* slabs, uint32_t 
     out[wid] = *(const MsState*)(slabs + (size_t)wid * L.slab_bytes + L.state);
 }
 
+// Between two slices: move the clauses the workers exported during the last slice into the global
+// ring, once each (a 64-bit order-independent signature in a hash set filters what many workers
+// learnt alike).  One thread per worker; nothing else runs on the stream meanwhile.
+__device__ inline unsigned long long share_mix(unsigned long long x) {
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__global__ void ms_share_collect_kernel(MsLayout L, char* slabs, uint32_t n_workers, int32_t* pool, uint32_t slots,
+                                        unsigned long long* share_n, unsigned long long* hash, uint32_t hash_mask,
+                                        uint32_t* intake, uint32_t intake_cap) {
+    const uint32_t wid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wid >= n_workers) return;
+    char* slab = slabs + (size_t)wid * L.slab_bytes;
+    MsState* st = (MsState*)(slab + L.state);
+    const uint32_t n = st->exp_n;
+    if (!n) return;
+    const int32_t* exp = (const int32_t*)(slab + L.exp);
+    for (uint32_t r = 0; r < n && r < MS_EXPORT_RECS; r++) {
+        const int32_t* rec = exp + r * MS_SHARE_REC;
+        const int sz = rec[0] & 15;
+        if (sz < 1 || sz > MS_SHARE_MAXLEN) continue;
+        unsigned long long h = (unsigned long long)sz * 0xd6e8feb86659fd93ull;
+        for (int j = 0; j < sz; j++) h += share_mix((unsigned long long)(uint32_t)rec[1 + j]);
+        if (!h) h = 1;
+        bool fresh = true;
+        uint32_t i = (uint32_t)(h >> 20) & hash_mask;
+        for (int probe = 0; probe < 16; probe++) {
+            unsigned long long prev = atomicCAS(&hash[i], 0ull, h);
+            if (prev == 0ull) break;
+            if (prev == h) { fresh = false; break; }
+            i = (i + 1) & hash_mask;
+        }
+        if (!fresh) continue;
+        // every worker attaches every record: units and binaries always pass, of the longer clauses only
+        // intake_cap per collection (first come), so that attaching stays a small part of a slice
+        if (sz > 2 && atomicAdd(intake, 1u) >= intake_cap) continue;
+        const unsigned long long slot = atomicAdd(share_n, 1ull) % slots;
+        int32_t* dst = pool + slot * MS_SHARE_REC;
+        for (int j = 0; j < MS_SHARE_REC; j++) dst[j] = rec[j];
+    }
+    st->exp_n = 0;
+}
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -188,6 +233,12 @@ struct mi355sat {
     DevBuf<int32_t> d_any_done, d_assump, d_script, d_proof;
     DevBuf<uint32_t> d_proof_len;
     DevBuf<uint64_t> d_assump_off, d_script_off;
+    // learnt-clause exchange between workers (layout.h MS_SHARE_*)
+    DevBuf<int32_t> d_share_pool;
+    DevBuf<unsigned long long> d_share_n, d_share_hash;
+    DevBuf<uint32_t> d_share_intake;
+    uint32_t share_slots = 0, share_hash_n = 0;
+    uint64_t share_slices = 0;
     MsShared sh{};
     MsLayout L{};
     uint32_t n_workers = 0;
@@ -196,6 +247,7 @@ struct mi355sat {
     bool trivially_unsat = false;
     std::vector<int8_t> fixed;                 // per var: 0 free, 1 true, -1 false (level-0 facts)
     uint32_t n_vars = 0;
+    std::vector<uint32_t> perm;                // caller's variable index -> device variable index (Prepared::perm)
     struct SweepHolder* sweep = nullptr;        // stepwise sweep in progress (mi355sat_sweep_*)
 };
 
@@ -206,6 +258,7 @@ struct Prepared {
     uint32_t n_vars = 0;
     bool unsat = false;
     std::vector<int32_t> units;                 // internal literals fixed at level 0 (trail prefix)
+    std::vector<uint32_t> perm;                 // caller's variable index (0-based) -> device variable index
     bool units_propagated = false;              // true if simplification ran (queue starts empty)
     std::vector<MsClauseHdr> cl_hdr;            // long clauses (>= 4 literals)
     std::vector<int32_t> cl_lits;               // each clause 16-byte aligned, padded with its first literal
@@ -216,6 +269,72 @@ struct Prepared {
 };
 
 inline int32_t to_internal(int32_t d) { return d > 0 ? 2 * (d - 1) : 2 * (-d - 1) + 1; }
+inline int32_t to_device(const std::vector<uint32_t>& perm, int32_t d) {   // DIMACS literal -> device literal
+    return d > 0 ? 2 * (int32_t)perm[d - 1] : 2 * (int32_t)perm[-d - 1] + 1;
+}
+
+// Variable order for the device: every per-variable array (the 2-bit assignment: 256 variables per
+// 64-byte line; records, watch and list headers: 4 per line) is gathered by variable index, so
+// variables that meet in clauses should be neighbours.  The caller's numbering is by encoder family;
+// this one grows blobs of 256 variables breadth-first through the clauses (variable - clause -
+// variable), each new blob seeded on the border of an earlier one, so a blob is a compact patch of the
+// variable interaction graph (for the support grids: a few neighbouring tiles with all their
+// variables, or a subtree of the totalizer).  Fixed and unused variables go last.
+void locality_order(uint32_t nv, const std::vector<int32_t>& nl, const std::vector<uint64_t>& no,
+                    const std::vector<int8_t>& val, std::vector<uint32_t>& perm) {
+    const uint32_t NONE = 0xffffffffu, BLOB = 256;
+    const size_t nn = no.size() - 1;
+    perm.assign(nv, NONE);
+    std::vector<uint32_t> occ_off((size_t)nv + 1, 0);
+    for (size_t c = 0; c < nn; c++) {
+        if (no[c + 1] - no[c] > 64) continue;
+        for (uint64_t k = no[c]; k < no[c + 1]; k++) occ_off[(nl[k] >> 1) + 1]++;
+    }
+    for (size_t i = 0; i < nv; i++) occ_off[i + 1] += occ_off[i];
+    std::vector<uint32_t> occ(occ_off[nv]), fill(occ_off.begin(), occ_off.end() - 1);
+    for (size_t c = 0; c < nn; c++) {
+        if (no[c + 1] - no[c] > 64) continue;
+        for (uint64_t k = no[c]; k < no[c + 1]; k++) occ[fill[nl[k] >> 1]++] = (uint32_t)c;
+    }
+    std::vector<uint32_t> vstamp(nv, 0), cstamp(nn, 0), frontier, q;
+    std::vector<uint8_t> pending(nv, 0);
+    size_t fhead = 0;
+    uint32_t next = 0, blob = 0, scan = 0;
+    for (;;) {
+        uint32_t seed = NONE;
+        while (fhead < frontier.size()) { uint32_t v = frontier[fhead++]; if (perm[v] == NONE) { seed = v; break; } }
+        if (seed == NONE) {
+            while (scan < nv && (perm[scan] != NONE || val[scan] != 0 || occ_off[scan] == occ_off[scan + 1])) scan++;
+            if (scan == nv) break;
+            seed = scan;
+        }
+        blob++;
+        q.clear();
+        q.push_back(seed);
+        vstamp[seed] = blob;
+        size_t h = 0;
+        uint32_t cnt = 0;
+        while (h < q.size() && cnt < BLOB) {
+            const uint32_t v = q[h++];
+            perm[v] = next++;
+            cnt++;
+            for (uint32_t e = occ_off[v]; e < occ_off[v + 1]; e++) {
+                const uint32_t c = occ[e];
+                if (cstamp[c] == blob) continue;
+                cstamp[c] = blob;
+                for (uint64_t k = no[c]; k < no[c + 1]; k++) {
+                    const uint32_t u = (uint32_t)(nl[k] >> 1);
+                    if (perm[u] != NONE || vstamp[u] == blob || val[u] != 0) continue;
+                    vstamp[u] = blob;
+                    q.push_back(u);
+                }
+            }
+        }
+        for (; h < q.size(); h++)   // the blob is full: its border seeds later blobs
+            if (!pending[q[h]]) { pending[q[h]] = 1; frontier.push_back(q[h]); }
+    }
+    for (uint32_t v = 0; v < nv; v++) if (perm[v] == NONE) perm[v] = next++;
+}
 
 void prepare(const mi355sat& s, bool simplify, Prepared& P) {
     const uint32_t nv = (uint32_t)s.max_var;
@@ -296,6 +415,11 @@ void prepare(const mi355sat& s, bool simplify, Prepared& P) {
         no.swap(no2);
         nn = no.size() - 1;
     }
+    // device variable order
+    if (s.opts.var_order > 0) locality_order(nv, nl, no, val, P.perm);
+    else { P.perm.resize(nv); for (uint32_t v = 0; v < nv; v++) P.perm[v] = v; }
+    for (auto& l : nl) l = 2 * (int32_t)P.perm[l >> 1] | (l & 1);
+    for (auto& l : P.units) l = 2 * (int32_t)P.perm[l >> 1] | (l & 1);
     // split: binary -> implication CSR, ternary -> pair CSR, >= 4 literals -> watched clauses
     std::vector<std::pair<int32_t, int32_t>> bins;
     std::vector<std::array<int32_t, 3>> terns;
@@ -396,6 +520,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     place(L.overflow, 4 * 3 * MS_OVERFLOW_CAP);
     place(L.assumps, 4 * (size_t)std::max<uint32_t>(assump_cap, 1));
     place(L.script, 4 * (size_t)std::max<uint32_t>(script_cap, 1));
+    place(L.exp, 4 * (size_t)MS_EXPORT_RECS * MS_SHARE_REC);
     // the big, cold-tailed arrays last
     place(L.lc_lits, 4 * (size_t)L.learnt_lit_cap);
     place(L.pool, 8 * (size_t)L.pool_cap);
@@ -418,9 +543,10 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     uint32_t* val = (uint32_t*)(T + L.val);      // zero = every variable unassigned
     MsVarRec* vrec = (MsVarRec*)(T + L.vrec);
     int32_t* vm_order = (int32_t*)(T + L.vm_order);
-    for (uint32_t v = 0; v < nv; v++) {
-        vrec[v] = MsVarRec{0, MS_REASON_NONE, (int32_t)(nv - 1 - v), /*phase=*/1, /*seen=*/0, 0, 0};
-        vm_order[nv - 1 - v] = (int32_t)v;
+    for (uint32_t e = 0; e < nv; e++) {   // initial decision order: the caller's numbering, highest first
+        const uint32_t v = P.perm[e];
+        vrec[v] = MsVarRec{0, MS_REASON_NONE, (int32_t)(nv - 1 - e), /*phase=*/1, /*seen=*/0, 0, 0};
+        vm_order[nv - 1 - e] = (int32_t)v;
     }
     int32_t* trail = (int32_t*)(T + L.trail);
     for (size_t i = 0; i < P.units.size(); i++) {
@@ -447,6 +573,7 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     std::vector<char> tmpl;
     build_layout_and_template(s, P, assump_cap, script_cap, tmpl);
     s.n_vars = P.n_vars;
+    s.perm = P.perm;
     s.d_cl_hdr.upload(P.cl_hdr.empty() ? std::vector<MsClauseHdr>{MsClauseHdr{0, 0}} : P.cl_hdr, s.stream);
     s.d_cl_lits.upload(P.cl_lits, s.stream);
     s.d_lit_hdr.upload(P.lit_hdr.empty() ? std::vector<MsLitHdr>{MsLitHdr{0, 0, 0, 0}} : P.lit_hdr, s.stream);
@@ -479,6 +606,16 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.d_slabs.alloc((size_t)W * s.L.slab_bytes);
     s.d_states.alloc(W);
     s.d_any_done.alloc(1);
+    // clause exchange: on unless switched off, whenever there is more than one worker and no proof is logged
+    s.share_slots = 0;
+    if (s.opts.share >= 0 && W > 1 && s.proof_path.empty() && script_cap == 0) {
+        s.share_slots = 1u << 20;
+        s.share_hash_n = 1u << 22;
+        s.d_share_pool.alloc((size_t)s.share_slots * MS_SHARE_REC);
+        s.d_share_n.alloc(1);
+        s.d_share_hash.alloc(s.share_hash_n);
+        s.d_share_intake.alloc(1);
+    }
     HIPCHK(hipStreamSynchronize(s.stream));
     if (s.opts.verbose)
         fprintf(stderr, "[mi355sat] vars=%u long=%u tern=%zu bin=%zu units=%zu slab=%.2f MiB workers=%u lds_val=%d\n", P.n_vars,
@@ -495,6 +632,11 @@ void reset_workers(mi355sat& s) {
                        s.d_slabs.p, (uint64_t)L.slab_bytes, (uint64_t)head, (uint64_t)L.pool, (uint64_t)(8 * s.pool_init));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(s.d_any_done.p, 0, sizeof(int32_t), s.stream));
+    if (s.share_slots) {
+        HIPCHK(hipMemsetAsync(s.d_share_n.p, 0, sizeof(unsigned long long), s.stream));
+        HIPCHK(hipMemsetAsync(s.d_share_hash.p, 0, sizeof(unsigned long long) * s.share_hash_n, s.stream));
+        s.share_slices = 0;
+    }
 }
 
 void customize(mi355sat& s, const std::vector<int32_t>* assump, const std::vector<uint64_t>* assump_off,
@@ -538,7 +680,10 @@ void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
     o.n_deq += props; o.n_watch += nw; o.n_cl_lit += ncl; o.n_move += nm; o.n_enq += ne;
     o.learnts = learnts; o.learnt_literals = llits;
     o.bcp_steps += steps; o.bcp_requeued += redo;
-    for (int i = 0; i < 6; i++) o.reserved[i] = 0;
+    uint64_t exported = 0, imported = 0, imported_units = 0;
+    for (auto& st : sts) { exported += st.n_exported; imported += st.n_imported; imported_units += st.n_imported_units; }
+    o.shared_exported += exported; o.shared_imported += imported; o.shared_imported_units += imported_units;
+    for (int i = 0; i < 3; i++) o.reserved[i] = 0;
     uint64_t prof[10] = {0}, cyc = 0;
     for (auto& st : sts) { for (int i = 0; i < 10; i++) prof[i] += st.prof[i]; cyc += st.slice_cycles; }
     if (prof[0] && s.opts.verbose) {
@@ -558,7 +703,7 @@ void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_
                          4 * (((size_t)s.n_vars + 15) / 16), hipMemcpyDeviceToHost));
     out.assign(n_vars_out, 0);
     for (uint64_t v = 0; v < n_vars_out && v < s.n_vars; v++)
-        out[v] = asg_of(words.data(), v) == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
+        out[v] = asg_of(words.data(), s.perm[v]) == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
 }
 
 struct SliceResult { float ms; };
@@ -581,6 +726,15 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     prm.proof_cap = (uint32_t)s.d_proof.n;
     prm.reduce_first = s.opts.reduce_first > 0 ? (uint32_t)s.opts.reduce_first : 2000u;
     prm.reduce_inc = s.opts.reduce_inc > 0 ? (uint32_t)s.opts.reduce_inc : 300u;
+    const bool share = mode == 0 && s.share_slots != 0;
+    const uint32_t share_intake_cap = (uint32_t)std::max(16, slice_ms > 0 ? 16 * slice_ms : 256);   // 16 clauses per ms of slice
+    if (share) {
+        prm.share_pool = s.d_share_pool.p;
+        prm.share_n = s.d_share_n.p;
+        prm.share_slots = s.share_slots;
+        prm.share_max_lbd = s.opts.share_lbd > 0 ? (uint32_t)s.opts.share_lbd : 2u;
+        prm.share_interval = s.opts.share_interval > 0 ? (uint32_t)s.opts.share_interval : 0xffffffffu;
+    }
     const uint32_t dyn = s.lds_val ? s.lds_val_bytes : 0;
     HIPCHK(hipEventRecord(s.ev0, s.stream));
     if (mode == 0) {
@@ -592,6 +746,15 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.ev1, s.stream));
+    if (share) {
+        if ((++s.share_slices & 255) == 0)   // forget old signatures before the set fills up (a clause may then be passed on twice)
+            HIPCHK(hipMemsetAsync(s.d_share_hash.p, 0, sizeof(unsigned long long) * s.share_hash_n, s.stream));
+        HIPCHK(hipMemsetAsync(s.d_share_intake.p, 0, sizeof(uint32_t), s.stream));
+        hipLaunchKernelGGL(ms_share_collect_kernel, dim3((s.n_workers + 63) / 64), dim3(64), 0, s.stream, s.L, s.d_slabs.p,
+                           s.n_workers, s.d_share_pool.p, s.share_slots, s.d_share_n.p, s.d_share_hash.p, s.share_hash_n - 1,
+                           s.d_share_intake.p, share_intake_cap);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventSynchronize(s.ev1));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, s.ev0, s.ev1));
@@ -609,9 +772,11 @@ void write_proof(mi355sat& s, bool unsat) {
     if (n > s.d_proof.n) { fclose(f); throw HipErr{"proof buffer overflow (derivation too long to log)"}; }
     std::vector<int32_t> buf(n);
     if (n) HIPCHK(hipMemcpy(buf.data(), s.d_proof.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> inv(s.perm.size());
+    for (uint32_t e = 0; e < s.perm.size(); e++) inv[s.perm[e]] = e;
     for (uint32_t i = 0; i < n; i++) {
         if (buf[i] < 0) fputs("0\n", f);
-        else fprintf(f, "%d ", (buf[i] & 1) ? -((buf[i] >> 1) + 1) : ((buf[i] >> 1) + 1));
+        else fprintf(f, "%d ", (buf[i] & 1) ? -((int)inv[buf[i] >> 1] + 1) : ((int)inv[buf[i] >> 1] + 1));
     }
     if (unsat) fputs("0\n", f);
     fclose(f);
@@ -627,10 +792,15 @@ const char* status_text(int st) {
 }
 
 // Shared driver for solve(), solve_batch() and the stepwise sweep API.
-// instance of worker w = w % n_instances.
+// Worker w starts on instance w % n_instances; workers of decided (or withdrawn) instances move on
+// to the open ones (w_inst).
 struct Sweep {
     uint32_t n_instances = 0;
     std::vector<int32_t> results, winner;
+    std::vector<uint8_t> dropped;                // withdrawn by the caller: result stays INTERRUPTED, counts as decided
+    std::vector<int32_t> base_assump;            // internal literals
+    std::vector<uint64_t> base_off;
+    uint64_t n_moved = 0;
     uint32_t decided = 0;
     bool stop_at_first = false;
     bool active = false;
@@ -658,6 +828,8 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     sw.active = false;
     sw.results.assign(n_instances, MI355SAT_INTERRUPTED);
     sw.winner.assign(n_instances, -1);
+    sw.dropped.assign(n_instances, 0);
+    sw.n_moved = 0;
     if (P.unsat) {
         std::fill(sw.results.begin(), sw.results.end(), MI355SAT_UNSAT);
         sw.decided = n_instances;
@@ -681,7 +853,7 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     for (size_t i = 0; i < assump.size(); i++) {
         int32_t d = assump[i];
         if (d == 0 || (uint64_t)(d < 0 ? -(int64_t)d : d) > P.n_vars) throw HipErr{"assumption literal out of range"};
-        a_int[i] = to_internal(d);
+        a_int[i] = to_device(P.perm, d);
     }
     uint32_t max_assumps = 0;
     for (uint32_t i = 0; i < n_instances; i++)
@@ -694,6 +866,8 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     customize(s, &a_int, &assump_off, nullptr, nullptr, n_instances, sw.split ? (int32_t)n_instances : -1);
     HIPCHK(hipStreamSynchronize(s.stream));
     const uint32_t W = s.n_workers;
+    sw.base_assump = a_int;
+    sw.base_off = assump_off;
     sw.w_inst.assign(W, 0);
     sw.w_cube.assign(W, {});
     sw.w_busy.assign(W, 0);
@@ -772,6 +946,55 @@ void schedule_cubes(mi355sat& s, Sweep& sw) {
     HIPCHK(hipStreamSynchronize(s.stream));
 }
 
+inline bool inst_open(const Sweep& sw, uint32_t inst) { return sw.results[inst] == MI355SAT_INTERRUPTED && !sw.dropped[inst]; }
+
+// Portfolio mode, between two slices: the workers of instances that are decided (or withdrawn) move to
+// the open instances with the fewest workers.  They keep their learnt clauses (consequences of the
+// formula alone) and only swap their assumption list; the worker holding a SAT instance's model stays.
+void rebalance_workers(mi355sat& s, Sweep& sw) {
+    const uint32_t W = s.n_workers, n_instances = sw.n_instances;
+    std::vector<uint32_t> cnt(n_instances, 0), movable;
+    for (uint32_t w = 0; w < W; w++) {
+        const uint32_t inst = (uint32_t)sw.w_inst[w];
+        const int st = sw.sts[w].status;
+        if (inst_open(sw, inst)) { if (st == MS_ST_RUNNING) cnt[inst]++; continue; }
+        if (sw.winner[inst] == (int32_t)w && sw.results[inst] == MI355SAT_SAT) continue;   // keeps the model
+        if (st == MS_ST_RUNNING || st == MS_ST_SAT || st == MS_ST_REFUTED || st == MS_ST_PARKED) movable.push_back(w);
+    }
+    std::vector<uint32_t> open;
+    for (uint32_t i = 0; i < n_instances; i++) if (inst_open(sw, i)) open.push_back(i);
+    std::vector<int32_t> upd, data;
+    auto park = [&](uint32_t w) {
+        if (sw.sts[w].status != MS_ST_RUNNING) return;
+        upd.insert(upd.end(), {(int32_t)w, MS_ST_PARKED, 0, 0, (int32_t)data.size()});
+        sw.sts[w].status = MS_ST_PARKED;
+        sw.w_busy[w] = 0;
+    };
+    if (open.empty() || s.opts.rebalance < 0) {
+        for (uint32_t w : movable) park(w);
+    } else {
+        for (uint32_t w : movable) {
+            uint32_t best = open[0];
+            for (uint32_t i : open) if (cnt[i] < cnt[best]) best = i;
+            cnt[best]++;
+            sw.w_inst[w] = (int32_t)best;
+            sw.w_busy[w] = 1;
+            sw.w_cube[w].assign(sw.base_assump.begin() + sw.base_off[best], sw.base_assump.begin() + sw.base_off[best + 1]);
+            upd.insert(upd.end(), {(int32_t)w, MS_ST_RUNNING, 1, (int32_t)sw.w_cube[w].size(), (int32_t)data.size()});
+            data.insert(data.end(), sw.w_cube[w].begin(), sw.w_cube[w].end());
+            sw.sts[w].status = MS_ST_RUNNING;
+            sw.n_moved++;
+        }
+    }
+    if (upd.empty()) return;
+    sw.d_upd.upload(upd, s.stream);
+    sw.d_data.upload(data.empty() ? std::vector<int32_t>{0} : data, s.stream);
+    hipLaunchKernelGGL(ms_assign_kernel, dim3((uint32_t)(upd.size() / 5)), dim3(64), 0, s.stream, s.L, s.d_slabs.p,
+                       (uint32_t)(upd.size() / 5), sw.d_upd.p, sw.d_data.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s.stream));
+}
+
 // One slice of the search kernel over all workers.  Returns 0 or a negative error.
 int sweep_step(mi355sat& s, Sweep& sw) {
     if (!sw.active) return 0;
@@ -794,7 +1017,12 @@ int sweep_step(mi355sat& s, Sweep& sw) {
             sw.open[inst]--;
             sw.n_closed++;
         }
-        if (sw.results[inst] != MI355SAT_INTERRUPTED) continue;
+        if (st.status == MS_ST_UNSAT) {   // refuted without any decision: the formula itself, whatever the assumptions
+            for (uint32_t i = 0; i < n_instances; i++)
+                if (inst_open(sw, i)) { sw.results[i] = MI355SAT_UNSAT; sw.winner[i] = (int32_t)w; sw.decided++; }
+            continue;
+        }
+        if (!inst_open(sw, inst)) continue;
         if (st.status == MS_ST_SAT) { sw.results[inst] = MI355SAT_SAT; sw.winner[inst] = (int32_t)w; sw.decided++; }
         else if (st.status == MS_ST_UNSAT || (st.status == MS_ST_REFUTED && (!sw.split || sw.open[inst] == 0))) {
             // the formula itself refuted, or (with splitting) the last open cube of the instance closed;
@@ -816,20 +1044,7 @@ int sweep_step(mi355sat& s, Sweep& sw) {
     HIPCHK(hipMemsetAsync(s.d_any_done.p, 0, sizeof(int32_t), s.stream));
     if (sw.decided == n_instances || (sw.stop_at_first && sw.decided > 0)) return 0;
     if (sw.split) schedule_cubes(s, sw);
-    else if (n_instances > 1 && sw.decided > 0) {
-        // portfolio mode: park the still-running workers of decided instances
-        for (uint32_t w = 0; w < s.n_workers; w++) {
-            uint32_t inst = w % n_instances;
-            if (sw.results[inst] != MI355SAT_INTERRUPTED && sw.sts[w].status == MS_ST_RUNNING) {
-                int32_t parked = MS_ST_PARKED;
-                HIPCHK(hipMemcpyAsync(s.d_slabs.p + (size_t)w * s.L.slab_bytes + s.L.state + offsetof(MsState, status),
-                                      &parked, sizeof parked, hipMemcpyHostToDevice, s.stream));
-                sw.sts[w].status = MS_ST_PARKED;
-                sw.w_busy[w] = 0;
-            }
-        }
-        HIPCHK(hipStreamSynchronize(s.stream));
-    }
+    else if (n_instances > 1 && sw.decided > 0) rebalance_workers(s, sw);
     return 0;
 }
 
@@ -1069,7 +1284,7 @@ int mi355sat_propagate_batch(mi355sat* s, const int32_t* decisions, const uint64
         for (uint64_t k = 0; k < soff.back(); k++) {
             int32_t d = decisions[decision_offsets[0] + k];
             if (d == 0 || (uint64_t)(d < 0 ? -(int64_t)d : d) > P.n_vars) throw HipErr{"decision literal out of range"};
-            script[k] = to_internal(d);
+            script[k] = to_device(P.perm, d);
         }
         upload_formula(*s, P, 0, max_script, (uint32_t)n_instances);
         if (s->n_workers < n_instances) throw HipErr{"not enough device memory for the batch"};
@@ -1107,7 +1322,7 @@ int mi355sat_propagate_batch(mi355sat* s, const int32_t* decisions, const uint64
                                    n_instances, hipMemcpyDeviceToHost));
             for (uint64_t i = 0; i < n_instances; i++)
                 for (uint64_t v = 0; v < n_vars; v++) {
-                    uint8_t x = v < P.n_vars ? asg_of(raw.data() + i * nw, v) : MS_ASG_UNDEF;
+                    uint8_t x = v < P.n_vars ? asg_of(raw.data() + i * nw, P.perm[v]) : MS_ASG_UNDEF;
                     out_values[i * n_vars + v] = x == MS_ASG_TRUE ? 1 : (x == MS_ASG_FALSE ? -1 : 0);
                 }
         }
@@ -1156,6 +1371,28 @@ int mi355sat_sweep_step(mi355sat* s, int32_t* results_out, uint64_t* n_decided) 
         s->stats.solve_seconds = keep.solve_seconds + (now_s() - t0);
         accumulate_stats(*s, sw.sts);
         return rc;
+    } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
+    catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
+}
+
+int mi355sat_sweep_drop(mi355sat* s, const uint64_t* instances, uint64_t n) {
+    if (!s || !s->sweep || (n && !instances)) return MI355SAT_ERR_STATE;
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        Sweep& sw = s->sweep->sw;
+        bool any = false;
+        for (uint64_t j = 0; j < n; j++) {
+            if (instances[j] >= sw.n_instances) { s->err = "instance out of range"; return MI355SAT_ERR_ARG; }
+            if (!inst_open(sw, (uint32_t)instances[j])) continue;
+            sw.dropped[instances[j]] = 1;
+            sw.decided++;
+            any = true;
+        }
+        if (any && sw.active && !sw.split && sw.decided < sw.n_instances) {
+            if (sw.sts.size() != s->n_workers) gather_states(*s, sw.sts);
+            rebalance_workers(*s, sw);
+        }
+        return 0;
     } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
     catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
 }

@@ -37,7 +37,8 @@ class Mi355SatOpts(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("workers", ctypes.c_int32), ("conflict_budget", ctypes.c_int64),
                 ("slice_conflicts", ctypes.c_int32), ("seed", ctypes.c_uint64), ("verbose", ctypes.c_int32),
                 ("reduce_first", ctypes.c_int32), ("reduce_inc", ctypes.c_int32), ("lds_val", ctypes.c_int32),
-                ("max_groups", ctypes.c_int32), ("slice_ms", ctypes.c_int32), ("cube_split", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+                ("max_groups", ctypes.c_int32), ("slice_ms", ctypes.c_int32), ("cube_split", ctypes.c_int32), ("share", ctypes.c_int32), ("share_lbd", ctypes.c_int32),
+                ("share_interval", ctypes.c_int32), ("var_order", ctypes.c_int32), ("rebalance", ctypes.c_int32)]
 
 
 class Mi355SatStats(ctypes.Structure):
@@ -49,7 +50,7 @@ class Mi355SatStats(ctypes.Structure):
                [(n, ctypes.c_uint64) for n in
                 ("n_deq", "n_watch", "n_cl_lit", "n_move", "n_enq", "n_sat", "n_unsat", "n_terminated",
                  "bcp_steps", "bcp_requeued")] + \
-               [("reserved", ctypes.c_uint64 * 6)]
+               [("shared_exported", ctypes.c_uint64), ("shared_imported", ctypes.c_uint64), ("shared_imported_units", ctypes.c_uint64), ("reserved", ctypes.c_uint64 * 3)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
@@ -77,6 +78,7 @@ def _bind(L):
     L.mi355sat_sweep_begin.argtypes = [vp, vp, vp, ctypes.c_uint64]
     L.mi355sat_sweep_step.argtypes = [vp, vp, vp]
     L.mi355sat_sweep_end.argtypes = [vp]
+    L.mi355sat_sweep_drop.argtypes = [vp, vp, ctypes.c_uint64]
     L.mi355sat_propagate_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, ctypes.c_int32]
     L.mi355sat_val.argtypes = [vp, ctypes.c_int32]
     L.mi355sat_val.restype = ctypes.c_int32
@@ -109,7 +111,7 @@ class Interrupter:
 
 class Mi355Sat:
     def __init__(self, device=-1, workers=0, conflict_budget=0, slice_conflicts=0, seed=0, verbose=0,
-                 reduce_first=0, reduce_inc=0, lds_val=0, max_groups=0, slice_ms=0, cube_split=0, _lib_override=None):
+                 reduce_first=0, reduce_inc=0, lds_val=0, max_groups=0, slice_ms=0, cube_split=0, share=0, share_lbd=0, share_interval=0, rebalance=0, var_order=0, _lib_override=None):
         # _lib_override: test hook (the wavefront-emulator build under tests/emu); the product
         # always binds the HIP library and fails loudly without it.
         raw = _lib_override if _lib_override is not None else _lib.solver_lib()
@@ -118,7 +120,7 @@ class Mi355Sat:
         self._L = _bound[id(raw)]
         opts = Mi355SatOpts(device=device, workers=workers, conflict_budget=conflict_budget,
                             slice_conflicts=slice_conflicts, seed=seed, verbose=verbose,
-                            reduce_first=reduce_first, reduce_inc=reduce_inc, lds_val=lds_val, max_groups=max_groups, slice_ms=slice_ms, cube_split=cube_split)
+                            reduce_first=reduce_first, reduce_inc=reduce_inc, lds_val=lds_val, max_groups=max_groups, slice_ms=slice_ms, cube_split=cube_split, share=share, share_lbd=share_lbd, share_interval=share_interval, rebalance=rebalance, var_order=var_order)
         self._h = self._L.mi355sat_new(ctypes.byref(opts))
         if not self._h:
             raise SolverError("mi355sat_new failed: " + (self._L.mi355sat_last_error(None) or b"").decode())
@@ -190,6 +192,12 @@ class Mi355Sat:
         nd = ctypes.c_uint64(0)
         self._check(self._L.mi355sat_sweep_step(self._h, _p(res), ctypes.byref(nd)), "sweep_step")
         return [SolverResult(int(r)) for r in res], nd.value
+
+    def sweep_drop(self, instances):
+        """Withdraw instances (their answer is implied); their workers join the open ones."""
+        idx = np.asarray(list(instances), dtype=np.uint64)
+        if len(idx):
+            self._check(self._L.mi355sat_sweep_drop(self._h, _p(idx), len(idx)), "sweep_drop")
 
     def sweep_end(self):
         self._check(self._L.mi355sat_sweep_end(self._h), "sweep_end")
