@@ -73,9 +73,10 @@ typedef struct mi355sat_opts {
                                   own decision order; 1: idle workers steal sub-cubes of running ones between slices
                                   (correct but, as measured in round 1, slower: DESIGN.md) */
     int32_t share;             /* learnt-clause exchange between the workers of one GPU (units, binaries and clauses of
-                                  at most 7 literals with LBD <= share_lbd, passed on between kernel launches):
+                                  at most share_len literals with LBD <= share_lbd, passed on between kernel launches):
                                   0 = default (on), -1 = off.  Off automatically with one worker or a proof log. */
     int32_t share_lbd;         /* 0 = 2 */
+    int32_t share_len;         /* longest exchanged clause, <= 31; 0 = 31 */
     int32_t share_interval;    /* > 0: a worker with unseen exchanged clauses restarts to attach them after this many of its
                                   own conflicts; 0 = default: only at its own (Glucose) restarts - forced restarts measured
                                   3-10x slower on the rect 24x24 ladder */
@@ -118,6 +119,9 @@ typedef struct mi355sat_stats_t {
 mi355sat* mi355sat_new(const mi355sat_opts* opts);
 void mi355sat_free(mi355sat* s);
 const char* mi355sat_signature(void);                 /* Solve::signature */
+/* sizeof(mi355sat_opts) (returned) and sizeof(mi355sat_stats_t) (*stats_size) of THIS build: a binding whose
+ * mirror structs have other sizes was written against another header and must refuse to run. */
+uint64_t mi355sat_abi_sizes(uint64_t* stats_size);
 const char* mi355sat_last_error(const mi355sat* s);   /* s may be NULL (error of the last failed new) */
 
 /* --- clause input (Solve::add_cnf / add_clause_ref) ---------------------- */

@@ -50,8 +50,10 @@ def test_product_sources_never_touch_the_oracle():
 
 def test_signature_and_opts_struct_layout():
     from timberborn_support_solver_amd.solver import Mi355SatOpts, Mi355SatStats
-    assert ctypes.sizeof(Mi355SatOpts) == 80
-    assert ctypes.sizeof(Mi355SatStats) == 8 * (9 + 4 + 8 + 8)
     L = _lib.solver_lib()
+    L.mi355sat_abi_sizes.restype = ctypes.c_uint64
+    st_size = ctypes.c_uint64(0)
+    assert L.mi355sat_abi_sizes(ctypes.byref(st_size)) == ctypes.sizeof(Mi355SatOpts)     # the header's structs,
+    assert st_size.value == ctypes.sizeof(Mi355SatStats) == 8 * (9 + 4 + 8 + 8)           # as the compiler laid them out
     L.mi355sat_signature.restype = ctypes.c_char_p
     assert b"mi355sat" in L.mi355sat_signature()

@@ -1161,7 +1161,7 @@ struct LoopState {
     // clause exchange (share_pool == nullptr: off)
     const int4* share_pool;
     u64 share_n, share_pos, n_exported, n_imported, n_imported_units, last_import_confl;
-    uint32_t share_slots, share_max_lbd, share_interval, exp_n, wid;
+    uint32_t share_slots, share_max_lbd, share_max_len, share_interval, exp_n, wid;
 };
 
 // Attach the records of the global ring this worker has not seen yet.  Called at decision level 0
@@ -1175,55 +1175,33 @@ DEV void import_shared(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& 
     const u64 end = ls.share_n;
     if (end - pos > ls.share_slots) pos = end - ls.share_slots;   // the ring overwrote what we never read
     int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
-    int budget = 2048;   // records per call; the rest waits for the next restart
-    while (pos < end && budget > 0 && w.status == MS_ST_RUNNING) {
-        const u64 idx = pos + (u64)w.lane;
-        const bool have = idx < end;
-        int4 a = make_int4(0, 0, 0, 0), b = make_int4(0, 0, 0, 0);
-        if (have) {
-            const int4* r = ls.share_pool + (idx % ls.share_slots) * 2;
-            a = r[0];
-            b = r[1];
+    const int32_t* pool = (const int32_t*)ls.share_pool;
+    int budget = 4096;   // records per call; the rest waits for the next restart
+    for (; pos < end && budget > 0 && w.status == MS_ST_RUNNING; pos++, budget--) {
+        // one record per step, one literal per lane (records are 128 bytes: one coalesced load)
+        const int word = pool[(pos % ls.share_slots) * MS_SHARE_REC + (u64)(w.lane & (MS_SHARE_REC - 1))];
+        const int hdr = bcast(word, 0);
+        const int rn = hdr & 63, rl = (hdr >> 6) & 255;
+        if ((uint32_t)(hdr >> 14) == ls.wid || rn < 1 || rn > MS_SHARE_MAXLEN) continue;
+        const bool in = w.lane >= 1 && w.lane <= rn;
+        const int v = in ? lit_value<LV>(w, sh, L, word) : MS_VAL_FALSE;   // units attached before are visible
+        if (ballot(in && v == MS_VAL_TRUE)) continue;
+        const u64 free_m = ballot(in && v == MS_VAL_UNDEF);
+        const int cnt = popc64(free_m);
+        if (cnt == 0) { w.status = MS_ST_UNSAT; break; }        // falsified at level 0
+        if (cnt == 1) {
+            enqueue_uniform<LV>(w, sh, L, bcast(word, first_lane(free_m)), MS_REASON_NONE);
+            ls.n_imported_units++;
+        } else {
+            if (w.n_learnts > L.learnt_cap / 2 && cnt > 2) continue;   // store half full: only binaries
+            if ((free_m >> w.lane) & 1) learnt_buf[popc64(free_m & lanemask_lt(w.lane))] = word;
+            wave_fence();
+            // glue <= 2 would pin it for ever; an imported clause has to earn that here
+            if (add_learnt<LV>(w, sh, L, cnt, (uint32_t)(rl < 3 ? 3 : rl)) < 0) break;
         }
-        const int n = a.x & 15, lbd = (a.x >> 4) & 255;
-        bool act = have && n > 0 && (uint32_t)(a.x >> 12) != ls.wid;
-        if (act) {   // first look, one record per lane: most are already satisfied here
-            const int lits[MS_SHARE_MAXLEN] = {a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            bool sat = false;
-            for (int j = 0; j < MS_SHARE_MAXLEN; j++)
-                if (j < n && lit_value<LV>(w, sh, L, lits[j]) == MS_VAL_TRUE) sat = true;
-            act = !sat;
-        }
-        u64 m = ballot(act);
-        while (m && w.status == MS_ST_RUNNING) {
-            const int src = first_lane(m);
-            m &= m - 1;
-            const int rn = bcast(n, src), rl = bcast(lbd, src);
-            const int l0 = bcast(a.y, src), l1 = bcast(a.z, src), l2 = bcast(a.w, src), l3 = bcast(b.x, src),
-                      l4 = bcast(b.y, src), l5 = bcast(b.z, src), l6 = bcast(b.w, src);
-            const int mine = w.lane == 0 ? l0 : w.lane == 1 ? l1 : w.lane == 2 ? l2 : w.lane == 3 ? l3 : w.lane == 4 ? l4 : w.lane == 5 ? l5 : l6;
-            const bool in = w.lane < rn;
-            const int v = in ? lit_value<LV>(w, sh, L, mine) : MS_VAL_FALSE;   // units of this batch are visible
-            if (ballot(in && v == MS_VAL_TRUE)) continue;
-            const u64 free_m = ballot(in && v == MS_VAL_UNDEF);
-            const int cnt = popc64(free_m);
-            if (cnt == 0) { w.status = MS_ST_UNSAT; break; }        // falsified at level 0
-            if (cnt == 1) {
-                enqueue_uniform<LV>(w, sh, L, bcast(mine, first_lane(free_m)), MS_REASON_NONE);
-                ls.n_imported_units++;
-            } else {
-                if (w.n_learnts > L.learnt_cap / 2 && cnt > 2) continue;   // store half full: only binaries
-                if ((free_m >> w.lane) & 1) learnt_buf[popc64(free_m & lanemask_lt(w.lane))] = mine;
-                wave_fence();
-                // glue <= 2 would pin it for ever; an imported clause has to earn that here
-                if (add_learnt<LV>(w, sh, L, cnt, (uint32_t)(rl < 3 ? 3 : rl)) < 0) break;
-            }
-            ls.n_imported++;
-        }
-        pos += MS_WAVE;
-        budget -= MS_WAVE;
+        ls.n_imported++;
     }
-    ls.share_pos = pos < end ? pos : end;
+    ls.share_pos = pos;
 }
 
 // A conflict was found by propagate(): learn, backjump, assert (Glucose `search` conflict branch).
@@ -1253,11 +1231,11 @@ DEV_COLD bool on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         if (w.lane == 0) *ls.proof_len = o + (uint32_t)lr.n + 1;
         wave_fence();
     }
-    if (ls.share_pool && lr.n <= MS_SHARE_MAXLEN && (lr.n <= 2 || lr.lbd <= ls.share_max_lbd) && ls.exp_n < MS_EXPORT_RECS) {
+    if (ls.share_pool && lr.n <= (int)ls.share_max_len && (lr.n <= 2 || lr.lbd <= ls.share_max_lbd) && ls.exp_n < MS_EXPORT_RECS) {
         int32_t* rec = WK_PTR(int32_t, w, L, exp) + ls.exp_n * MS_SHARE_REC;
-        if (w.lane < MS_SHARE_REC)
-            rec[w.lane] = w.lane == 0 ? (int)((uint32_t)lr.n | ((lr.lbd > 255u ? 255u : lr.lbd) << 4) | (ls.wid << 12))
-                                      : (w.lane <= lr.n ? learnt_buf[w.lane - 1] : 0);
+        if (w.lane <= lr.n)
+            rec[w.lane] = w.lane == 0 ? (int)((uint32_t)lr.n | ((lr.lbd > 255u ? 255u : lr.lbd) << 6) | (ls.wid << 14))
+                                      : learnt_buf[w.lane - 1];
         ls.exp_n++;
         ls.n_exported++;
     }
@@ -1374,6 +1352,7 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     ls.share_pos = st->share_pos; ls.n_exported = st->n_exported; ls.n_imported = st->n_imported;
     ls.n_imported_units = st->n_imported_units; ls.last_import_confl = st->last_import_confl;
     ls.share_slots = prm.share_slots; ls.share_max_lbd = prm.share_max_lbd; ls.share_interval = prm.share_interval;
+    ls.share_max_len = prm.share_max_len < MS_SHARE_MAXLEN ? prm.share_max_len : MS_SHARE_MAXLEN;
     ls.exp_n = st->exp_n; ls.wid = wid;
     const int n_assumps_reg = ls.n_assumps;
     MsShared sc = sh;     // private copies for the cold calls (their address is taken)

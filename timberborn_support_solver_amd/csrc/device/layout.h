@@ -24,13 +24,13 @@
 #define MS_LBDQ 50                // Glucose restart window
 #define MS_MAX_GROUPS 16          // queue literals propagated per step (lane groups per wave)
 #define MS_SPLIT_MAX 8            // decisions a worker offers per slice for splitting its cube
-// Learnt-clause exchange between the workers of one GPU: fixed 32-byte records
-//   word 0 = size | lbd << 4 | producer << 12,  words 1..7 = literals
+// Learnt-clause exchange between the workers of one GPU: fixed 128-byte records
+//   word 0 = size | lbd << 6 | producer << 14,  words 1..31 = literals
 // A worker appends the short / low-LBD clauses it learns to its private export buffer; between two
 // slices ms_share_collect_kernel moves the new ones (deduplicated) into one global ring of records,
 // and every worker attaches the records it has not seen yet the next time it stands at level 0.
-#define MS_SHARE_REC 8            // int32 words per record
-#define MS_SHARE_MAXLEN 7         // longest clause that is exchanged
+#define MS_SHARE_REC 32           // int32 words per record
+#define MS_SHARE_MAXLEN 31        // longest clause that is exchanged
 #define MS_EXPORT_RECS 64         // per-worker export buffer (records per slice; more are dropped)
 
 // lit_value() results
@@ -172,7 +172,7 @@ struct MsParams {
     const int32_t* share_pool;     // ring of share_slots records
     const unsigned long long* share_n;  // records ever appended (constant during a slice)
     uint32_t share_slots;
-    uint32_t share_max_lbd;        // clauses with lbd <= this (or size <= 2) are exported
+    uint32_t share_max_lbd;        // clauses with lbd <= this (or size <= 2) and size <= share_max_len are exported
     uint32_t share_interval;       // a worker with unseen records restarts to import them after this many conflicts
-    uint32_t pad3;
+    uint32_t share_max_len;
 };

@@ -153,7 +153,7 @@ __global__ void ms_share_collect_kernel(MsLayout L, char* slabs, uint32_t n_work
     const int32_t* exp = (const int32_t*)(slab + L.exp);
     for (uint32_t r = 0; r < n && r < MS_EXPORT_RECS; r++) {
         const int32_t* rec = exp + r * MS_SHARE_REC;
-        const int sz = rec[0] & 15;
+        const int sz = rec[0] & 63;
         if (sz < 1 || sz > MS_SHARE_MAXLEN) continue;
         unsigned long long h = (unsigned long long)sz * 0xd6e8feb86659fd93ull;
         for (int j = 0; j < sz; j++) h += share_mix((unsigned long long)(uint32_t)rec[1 + j]);
@@ -172,7 +172,7 @@ __global__ void ms_share_collect_kernel(MsLayout L, char* slabs, uint32_t n_work
         if (sz > 2 && atomicAdd(intake, 1u) >= intake_cap) continue;
         const unsigned long long slot = atomicAdd(share_n, 1ull) % slots;
         int32_t* dst = pool + slot * MS_SHARE_REC;
-        for (int j = 0; j < MS_SHARE_REC; j++) dst[j] = rec[j];
+        for (int j = 0; j <= sz; j++) dst[j] = rec[j];
     }
     st->exp_n = 0;
 }
@@ -609,7 +609,7 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     // clause exchange: on unless switched off, whenever there is more than one worker and no proof is logged
     s.share_slots = 0;
     if (s.opts.share >= 0 && W > 1 && s.proof_path.empty() && script_cap == 0) {
-        s.share_slots = 1u << 20;
+        s.share_slots = 1u << 19;   // 64 MiB of records
         s.share_hash_n = 1u << 22;
         s.d_share_pool.alloc((size_t)s.share_slots * MS_SHARE_REC);
         s.d_share_n.alloc(1);
@@ -733,6 +733,7 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
         prm.share_n = s.d_share_n.p;
         prm.share_slots = s.share_slots;
         prm.share_max_lbd = s.opts.share_lbd > 0 ? (uint32_t)s.opts.share_lbd : 2u;
+        prm.share_max_len = s.opts.share_len > 0 ? (uint32_t)s.opts.share_len : (uint32_t)MS_SHARE_MAXLEN;
         prm.share_interval = s.opts.share_interval > 0 ? (uint32_t)s.opts.share_interval : 0xffffffffu;
     }
     const uint32_t dyn = s.lds_val ? s.lds_val_bytes : 0;
@@ -1078,6 +1079,11 @@ struct SweepHolder { Sweep sw; mi355sat_stats_t base; };
 
 // =============================================================================== C ABI
 extern "C" {
+
+uint64_t mi355sat_abi_sizes(uint64_t* stats_size) {
+    if (stats_size) *stats_size = sizeof(mi355sat_stats_t);
+    return sizeof(mi355sat_opts);
+}
 
 const char* mi355sat_signature(void) { return "mi355sat 0.1 (HIP/gfx950 wave-parallel CDCL)"; }
 
