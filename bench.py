@@ -149,8 +149,9 @@ def main():
     solver.close()
 
     # ---- wall-clock to first UNSAT on the largest rung that finishes in bench time (64x64 does not:
-    # SURVEY §6).  GPU: the whole sweep k_hi..0 as one batch over one CNF until the cut closes
-    # (max UNSAT k + 1 == min SAT k).  CPU: the reference's sequential loop (k := count - 1) on the oracle.
+    # SURVEY §6).  GPU: the product's own loop, solver_loop_sweep (first bound alone as the reference makes it,
+    # then every lower bound as one batch until max UNSAT k + 1 == min count).  CPU: the reference's
+    # sequential loop (k := count - 1) on the oracle.
     first_unsat = None
     if rank == 0 and world == 1 and args.first_unsat_size > 0 and not args.no_cpu:
         from oracle import oracle as ora
@@ -159,27 +160,13 @@ def main():
         g2 = WorldGrid.rect(m, m)
         e2 = Encoding.encode(defs, g2)
         k0 = max(4, m * m // 24)
-        c2 = e2.with_limits_into_cnf(PlatformLimits({(1, 1): k0}), sweep=True)
-        ks2 = list(range(k0, -1, -1))
-        sets2 = [([-int(c2.card_outputs[k])] if k < k0 else []) for k in ks2]
-        sv = Mi355Sat(device=device_index, workers=max(len(ks2), 4096 // len(ks2) * len(ks2)), slice_ms=10)
-        sv.add_cnf(c2.lits, c2.offsets)
+        from timberborn_support_solver_amd import solver_loop_sweep
         tg = time.perf_counter()
-        sv.sweep_begin(sets2)
-        kstar = None
-        while time.perf_counter() - tg < 120:
-            res2, _ = sv.sweep_step()
-            sat_k = min([k for k, r in zip(ks2, res2) if r == SolverResult.Sat], default=None)
-            unsat_k = max([k for k, r in zip(ks2, res2) if r == SolverResult.Unsat], default=None)
-            if sat_k is not None and unsat_k is not None and unsat_k + 1 >= sat_k:
-                kstar = sat_k
-                break
-            # implied by monotonicity: withdraw them, their workers join the open instances
-            sv.sweep_drop([i for i, k in enumerate(ks2) if res2[i] == SolverResult.Interrupted and
-                           ((sat_k is not None and k > sat_k) or (unsat_k is not None and k < unsat_k))])
+        hist = solver_loop_sweep(g2, e2, PlatformLimits({(1, 1): k0}), out=lambda line: None, time_limit=120,
+                                 make_solver=lambda: Mi355Sat(device=device_index, slice_ms=10))
         gpu_s = time.perf_counter() - tg
-        sv.sweep_end()
-        sv.close()
+        sat = [h for h in hist if h["result"] == SolverResult.Sat]
+        kstar = sat[-1]["count"] if sat and hist[-1]["result"] == SolverResult.Unsat and all(h["valid"] for h in sat) else None
         # CPU: decreasing-k loop, fresh solver per k (crates/repl/src/main.rs:290-346)
         tc = time.perf_counter()
         k, cpu_kstar = k0, None
@@ -196,7 +183,7 @@ def main():
             cnt = PlatformLayout.from_assignment(o.model(ck.n_vars)[:e2.n_vars], e2).platform_count()
             k = cnt - 1
         cpu_s = time.perf_counter() - tc
-        first_unsat = {"instance": f"rect {m} {m} {args.platforms}, sweep from k={k0}", "optimum_k": kstar,
+        first_unsat = {"instance": f"rect {m} {m} {args.platforms}, solver_loop_sweep from k={k0} (first bound alone, then all lower bounds as one batch)", "optimum_k": kstar,
                        "gpu_seconds": gpu_s if kstar is not None else None, "cpu_seconds": cpu_s if cpu_kstar is not None else None,
                        "cpu_optimum_k": cpu_kstar, "cpu_kind": "port (oracle CDCL restatement, 1 core)",
                        "note": "rect 64 64 to a proven first UNSAT is out of reach for both sides (area bound k* >= 43)"}
@@ -204,6 +191,17 @@ def main():
         kern_s = d["kernel_seconds"]
         launches = max(1, d["kernel_launches"])
         achieved = alg_bytes / max(kern_s, 1e-9) / 1e9
+        # HBM bytes per launch of the dominant kernel from the PMC passes (they cannot run inside this process:
+        # separate `rocprofv3 --pmc` runs of this same command; the committed summary is attached when this run is
+        # the configuration it was taken on)
+        traffic, traffic_src = None, None
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+        default_cfg = (n == 64 and args.k_lo == 44 and args.k_hi == 51 and workers == 4096 and args.slice_ms == 250 and
+                       args.platforms == "default" and args.share == 0 and args.var_order == 0)
+        if tfiles and default_cfg:
+            tj = json.load(open(tfiles[-1]))
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/" + os.path.basename(tfiles[-1])
         out = {
             "metric": "literal-propagations/sec + wall-clock to first UNSAT, 64x64 rect",
             "value": total_props / max_dt,
@@ -227,7 +225,7 @@ def main():
             "first_unsat_wall_clock_s": first_unsat["gpu_seconds"] if first_unsat else None,
             "first_unsat": first_unsat,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ms_search_kernel", "kernel_ms_avg": kern_s / launches * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "bytes_per_propagation": alg_bytes / max(1, props)},

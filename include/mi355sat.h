@@ -57,8 +57,8 @@ typedef struct mi355sat mi355sat;
  * A NULL pointer means all defaults. */
 typedef struct mi355sat_opts {
     int32_t device;            /* HIP device ordinal; -1 = current device (default 0) */
-    int32_t workers;           /* concurrent search workers (one wavefront each) for a plain
-                                  solve(); 0 = default */
+    int32_t workers;           /* concurrent search workers (one wavefront each); 0 = default: 4096 (16 per CU) above
+                                  100k clauses, 1024 above 20k, else 256 */
     int64_t conflict_budget;   /* per-solve conflict limit summed over workers; 0 = none.
                                   Exhausted budget -> MI355SAT_INTERRUPTED */
     int32_t slice_conflicts;   /* conflicts per worker per kernel launch; 0 = default */
@@ -157,6 +157,9 @@ int mi355sat_sweep_step(mi355sat* s, int32_t* results /* may be NULL */, uint64_
  * SAT one and every k below an UNSAT one is implied).  Their result stays 0, they count as decided, and
  * their workers move to the instances still open - as do the workers of every instance that gets its verdict. */
 int mi355sat_sweep_drop(mi355sat* s, const uint64_t* instances, uint64_t n);
+/* Model of an instance that already reported SAT, while the sweep is still running (the loop needs the
+ * layout's platform count to know which bounds it answers). */
+int mi355sat_sweep_model_of(mi355sat* s, uint64_t instance, int8_t* out, uint64_t n_vars);
 int mi355sat_sweep_end(mi355sat* s);
 
 /* Batched unit propagation (BCP only, no search): instance i enqueues its

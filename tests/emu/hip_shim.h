@@ -89,7 +89,14 @@ static inline int __builtin_amdgcn_readfirstlane(int v) {
 #define __builtin_amdgcn_fence(order, scope) emu::fence_rendezvous()
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 unsigned long long emu_ticks_100mhz();
-#define __builtin_amdgcn_s_memrealtime() emu_ticks_100mhz()
+// s_memrealtime is a scalar instruction: one value per wave.  The fibers of a wave run one after the other
+// here, so each would read a later clock and the lanes could disagree about "slice over" - lane 0's reading
+// is handed to all of them.
+static inline unsigned long long emu_uniform_ticks() {
+    emu::collective_begin(emu_ticks_100mhz(), 7);
+    return emu::collective_read(0);
+}
+#define __builtin_amdgcn_s_memrealtime() emu_uniform_ticks()
 #ifndef __clang__
 static inline unsigned long long __builtin_readcyclecounter() { return __builtin_ia32_rdtsc(); }
 #endif

@@ -43,6 +43,9 @@ def emu_lib():
     if _emu is None:
         import subprocess
         d = os.path.join(ROOT, "tests", "emu")
+        if os.environ.get("TBS_EMU_LIB"):     # e.g. the sanitizer build of tests/emu/asan.mk
+            _emu = ctypes.CDLL(os.environ["TBS_EMU_LIB"])
+            return _emu
         subprocess.check_call(["make", "-C", d, "libmi355sat_emu.so"], stdout=subprocess.DEVNULL)
         _emu = ctypes.CDLL(os.path.join(d, "libmi355sat_emu.so"))
     return _emu

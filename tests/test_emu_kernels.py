@@ -251,3 +251,18 @@ def test_emulated_sweep_moves_workers_to_open_instances_and_drops_implied_ones()
     for i, k in enumerate(ks):                          # whatever else was decided is consistent with k* = 4
         assert res[i] in (SolverResult.Interrupted, SolverResult.Sat if k >= 4 else SolverResult.Unsat)
     s.close()
+
+
+def test_emulated_solver_loop_sweep_prints_the_reference_messages():
+    from timberborn_support_solver_amd import solver_loop_sweep
+    grid = make_grid("ex1")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    lines = []
+    hist = solver_loop_sweep(grid, enc, PlatformLimits({(1, 1): 8}), out=lines.append,
+                             make_solver=lambda: emu_solver(workers=9, slice_conflicts=20))
+    sat = [h for h in hist if h["result"] == SolverResult.Sat]
+    assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == 2 and 1 <= len(sat) <= 2           # k* = 3
+    assert sat[-1]["count"] == 3 and all(h["valid"] for h in sat)
+    assert "Solution found (3 platforms total)" in lines and lines[-1] == "No solution found for the current constraints"
+    with pytest.raises(ValueError):
+        solver_loop_sweep(grid, enc, PlatformLimits({(1, 1): 3}, weights={(1, 1): 2}, weight_limit=5))

@@ -193,6 +193,12 @@ def test_cpp_solver_loop_cli_prints_the_reference_messages():
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and lines[-1] == "No solution found for the current constraints"
     assert [l for l in lines if l.startswith("Solution found")][-1] == "Solution found (4 platforms total)"   # k* = 4 with 1x1 only
+    # the same refinement as one batch on the device (solver_loop_sweep)
+    out = subprocess.run([cli, "rect", "16", "16", "-l1:40", "--workers", "512", "--sweep"], capture_output=True, text=True, timeout=120)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1] == "No solution found for the current constraints"
+    assert [l for l in lines if l.startswith("Solution found")][-1] == "Solution found (4 platforms total)"   # k* = 4
+    assert "Solution validation FAILED" not in lines
 
 
 def test_interrupt_and_budget():
@@ -298,3 +304,18 @@ def test_sweep_with_exchange_migration_and_withdrawn_instances_finds_the_cut():
         assert r in (SolverResult.Interrupted, SolverResult.Sat if k >= 4 else SolverResult.Unsat)
     assert s.stats()["shared_exported"] > 0
     s.close()
+
+
+@pytest.mark.parametrize("terrain,pset,k0,kstar", [("rect16x16", "default", 40, 4), ("ex3", "default", 20, 1), ("ex2", "default", 12, 4)])
+def test_solver_loop_sweep_reaches_the_same_optimum_as_the_sequential_loop(terrain, pset, k0, kstar):
+    from timberborn_support_solver_amd import solver_loop_sweep
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    lines = []
+    hist = solver_loop_sweep(grid, enc, PlatformLimits({(1, 1): k0}), out=lines.append, time_limit=120,
+                             make_solver=lambda: Mi355Sat(workers=1024, slice_ms=2))
+    sat = [h for h in hist if h["result"] == SolverResult.Sat]
+    assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == kstar - 1 and 1 <= len(sat) <= 2
+    assert sat[-1]["count"] == kstar and all(h["valid"] for h in sat)
+    assert f"Solution found ({kstar} platforms total)" in lines
+    assert lines[-1] == "No solution found for the current constraints"

@@ -1378,8 +1378,9 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
             slice_confl++;
             if (slice_confl >= prm.slice_conflicts) break;
             if ((slice_confl & 63) == 0) {
-                if (*prm.stop_flag) break;
-                if (prm.stop_on_any && *(volatile int32_t*)prm.any_done) break;
+                // one answer per wave (another thread / workgroup may write these while the wave reads them)
+                if (uni(*prm.stop_flag)) break;
+                if (prm.stop_on_any && uni(*(volatile int32_t*)prm.any_done)) break;
             }
         } else {
             if (w.status != MS_ST_RUNNING) break;

@@ -1,5 +1,5 @@
 // tbs_cli — minimal command-line driver of the solve path (NOT the reference's REPL/UI):
-//   tbs_cli rect W H [-l1:K] [--platforms default|1x1] [--workers N]
+//   tbs_cli rect W H [-l1:K] [--platforms default|1x1] [--workers N] [--sweep]
 //   tbs_cli file PATH.toml [-l1:K] ...
 // Mirrors `solve -l<dims>:<n>` of crates/repl/src/main.rs:44-75,248-261: encode once, then solver_loop.
 // Ctrl-C calls mi355sat_interrupt (main.rs:297-324).
@@ -12,7 +12,9 @@
 #include "solver_loop.hpp"
 
 static std::atomic<mi355sat*> g_current{nullptr};
+static std::atomic<int> g_interrupted{0};
 static void on_sigint(int) {
+    g_interrupted.store(1);
     mi355sat* s = g_current.load();
     if (s) mi355sat_interrupt(s);
 }
@@ -21,7 +23,7 @@ int main(int argc, char** argv) {
     using namespace tbs;
     try {
         if (argc < 3) {
-            fprintf(stderr, "usage: %s rect W H | file PATH [-l<dims>:<n>]... [--platforms default|1x1] [--workers N]\n", argv[0]);
+            fprintf(stderr, "usage: %s rect W H | file PATH [-l<dims>:<n>]... [--platforms default|1x1] [--workers N] [--sweep]\n", argv[0]);
             return 2;
         }
         WorldGrid grid;
@@ -33,6 +35,7 @@ int main(int argc, char** argv) {
         PlatformLimits limits;
         mi355sat_opts opts{};
         opts.device = -1;
+        bool sweep = false;
         for (; a < argc; a++) {
             std::string arg = argv[a];
             if (arg.rfind("-l", 0) == 0) {             // -l<dims>:<n>, dims = AxB or A (=AxA), main.rs:120-142
@@ -47,12 +50,14 @@ int main(int argc, char** argv) {
             } else if (arg == "--platforms" && a + 1 < argc) {
                 if (!strcmp(argv[++a], "1x1")) defs = {Dims{1, 1}};
             } else if (arg == "--workers" && a + 1 < argc) opts.workers = atoi(argv[++a]);
+            else if (arg == "--sweep") sweep = true;   // all bounds k0..0 as one batch on the device
             else throw std::runtime_error("unknown argument " + arg);
         }
         Encoding enc = Encoding::encode(defs, grid);
         signal(SIGINT, on_sigint);
-        auto hist = solver_loop(grid, enc, limits, &opts, [](const std::string& l) { std::cout << l << std::endl; },
-                                [](mi355sat* s) { g_current.store(s); });
+        auto print = [](const std::string& l) { std::cout << l << std::endl; };
+        auto hist = sweep ? solver_loop_sweep(grid, enc, limits, &opts, print, [](mi355sat* s) { g_current.store(s); }, &g_interrupted)
+                          : solver_loop(grid, enc, limits, &opts, print, [](mi355sat* s) { g_current.store(s); });
         return hist.empty() ? 1 : 0;
     } catch (const std::exception& e) {
         fprintf(stderr, "Error: %s\n", e.what());

@@ -34,6 +34,19 @@ SolverResult run_solver(const Cnf& cnf, const mi355sat_opts* opts, std::vector<i
 std::vector<LoopIteration> solver_loop(const WorldGrid& world, const Encoding& encoding, PlatformLimits limits,
                                        const mi355sat_opts* opts,
                                        const std::function<void(const std::string&)>& out,
-                                       const std::function<void(mi355sat*)>& on_interrupter = {});
+                                       const std::function<void(mi355sat*)>& on_interrupter = {},
+                                       size_t max_iterations = (size_t)-1);
+
+// The same refinement as ONE batch on the device: every bound k0, k0-1, ..., 0 is an assumption
+// set over one CNF built for k0; a SAT model with c platforms answers every bound >= c, an UNSAT bound every
+// bound below it (those instances are withdrawn, mi355sat_sweep_drop).  Done when max UNSAT k + 1 == min
+// count.  Prints the reference's messages for the iterations the sequential loop would still have to make
+// (the best layout, then the refuting bound).  The first iteration (the loose start bound) is made exactly as
+// the reference makes it; the batch covers count-1 .. 0.  Only the `-l1:K` form.
+std::vector<LoopIteration> solver_loop_sweep(const WorldGrid& world, const Encoding& encoding, const PlatformLimits& limits,
+                                             const mi355sat_opts* opts,
+                                             const std::function<void(const std::string&)>& out,
+                                             const std::function<void(mi355sat*)>& on_interrupter = {},
+                                             const std::atomic<int>* interrupted = nullptr);
 
 }  // namespace tbs

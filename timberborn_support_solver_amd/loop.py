@@ -66,6 +66,94 @@ def solver_loop(grid, encoding, limits, make_solver=None, out=print, on_interrup
     return history
 
 
+def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_interrupter=None, time_limit=None):
+    """The same refinement as ONE batch: every bound k0, k0-1, ..., 0 is an assumption set over one
+    CNF built for k0 (`with_limits_into_cnf(sweep=True)`), all solved concurrently on the device.  A SAT model
+    with c platforms answers every bound >= c, an UNSAT bound every bound below it; those instances are
+    withdrawn (`sweep_drop`) and their workers join the open ones.  Done when max UNSAT k + 1 == min count.
+    Prints what the reference loop prints for the iterations it would still have to make (the best layout,
+    then the refuting bound) and returns records shaped like solver_loop's.  Only the `-l1:K` form."""
+    if set(limits.card_limits) != {(1, 1)} or limits.weights or limits.weight_limit is not None:
+        raise ValueError("solver_loop_sweep handles a single 1x1 cardinality limit; use solver_loop / weight_loop")
+    # first iteration exactly as the reference makes it (the start bound is loose: its totalizer would only
+    # burden the batch); the batch then covers count-1 .. 0
+    first = solver_loop(grid, encoding, limits, make_solver=make_solver, out=out, on_interrupter=on_interrupter,
+                        max_iterations=1)
+    if first[-1]["result"] != SolverResult.Sat or not first[-1]["count"]:
+        return first
+    return first + _sweep_below(grid, encoding, first[-1]["count"] - 1, make_solver, out, on_interrupter, time_limit)
+
+
+def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limit):
+    cnf = encoding.with_limits_into_cnf(PlatformLimits({(1, 1): k0}), sweep=True)
+    ks = list(range(k0, -1, -1))
+    sets = [([-int(cnf.card_outputs[k])] if k < len(cnf.card_outputs) else []) for k in ks]
+    solver = (make_solver or (lambda: Mi355Sat()))()
+    solver.add_cnf(cnf.lits, cnf.offsets)
+    solver.reserve(cnf.n_vars)
+    flag = []
+    inner = solver.interrupter()
+
+    class _SweepInterrupter:   # the batch is driven from here, so the loop has to see the interrupt too
+        def interrupt(self):
+            flag.append(1)
+            inner.interrupt()
+
+    if on_interrupter:
+        on_interrupter(_SweepInterrupter())
+    t0 = time.perf_counter()
+    solver.sweep_begin(sets)
+    best_c, best_i, unsat_k, looked = None, None, -1, set()
+    interrupted = False
+    while True:
+        res, _ = solver.sweep_step()
+        for i, r in enumerate(res):
+            if r == SolverResult.Unsat:
+                unsat_k = max(unsat_k, ks[i])
+            elif r == SolverResult.Sat and i not in looked:
+                looked.add(i)
+                c = PlatformLayout.from_assignment(solver.sweep_solution_of(i, encoding.n_vars), encoding).platform_count()
+                if best_c is None or c < best_c:
+                    best_c, best_i = c, i
+        if best_c is not None and (unsat_k + 1 >= best_c or best_c == 0):
+            break
+        if all(r != SolverResult.Interrupted for r in res):
+            break
+        if flag or (time_limit is not None and time.perf_counter() - t0 > time_limit):
+            interrupted = True
+            break
+        solver.sweep_drop([i for i, k in enumerate(ks) if res[i] == SolverResult.Interrupted and
+                           ((best_c is not None and k >= best_c) or k < unsat_k)])
+    dt = time.perf_counter() - t0
+    layout = None
+    if best_i is not None:
+        layout = PlatformLayout.from_assignment(solver.sweep_solution_of(best_i, encoding.n_vars), encoding)
+    solver.sweep_end()
+    stats = solver.stats()
+    solver.close()
+    history = []
+    if layout is not None:
+        rec = {"k": k0, "result": SolverResult.Sat, "count": best_c, "valid": layout.validate(grid).is_valid(),
+               "seconds": dt, "stats": stats, "layout": layout}
+        history.append(rec)
+        if best_c == 0:
+            out("Found a solution with no platforms - aborting")
+            return history
+        out(f"Solution found ({best_c} platforms total)")
+        for (w, h), n in sorted(layout.platform_stats().items()):
+            out(f"{w}x{h}: {n}")
+        out("Solution validation OK" if rec["valid"] else "Solution validation FAILED")
+    if interrupted:
+        history.append({"k": (best_c - 1) if best_c else k0, "result": SolverResult.Interrupted, "count": None, "valid": None,
+                        "seconds": dt, "stats": stats})
+        out("Solver interrupted")
+    elif best_c is None or unsat_k + 1 >= best_c:
+        history.append({"k": unsat_k if best_c is None else best_c - 1, "result": SolverResult.Unsat, "count": None,
+                        "valid": None, "seconds": dt, "stats": stats})
+        out("No solution found for the current constraints")
+    return history
+
+
 def weight_loop(grid, encoding, limits, make_solver=None, out=print, max_iterations=None):
     """The GUI's weight-minimising loop (crates/gui/src/app.rs:148-175, 235-245): solve, take the layout
     (after run_trivial_optimization), set weight_limit = total_weight - 1 and solve again until Unsat /

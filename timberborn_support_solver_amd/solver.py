@@ -84,6 +84,7 @@ def _bind(L):
     L.mi355sat_sweep_step.argtypes = [vp, vp, vp]
     L.mi355sat_sweep_end.argtypes = [vp]
     L.mi355sat_sweep_drop.argtypes = [vp, vp, ctypes.c_uint64]
+    L.mi355sat_sweep_model_of.argtypes = [vp, ctypes.c_uint64, vp, ctypes.c_uint64]
     L.mi355sat_propagate_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, ctypes.c_int32]
     L.mi355sat_val.argtypes = [vp, ctypes.c_int32]
     L.mi355sat_val.restype = ctypes.c_int32
@@ -203,6 +204,13 @@ class Mi355Sat:
         idx = np.asarray(list(instances), dtype=np.uint64)
         if len(idx):
             self._check(self._L.mi355sat_sweep_drop(self._h, _p(idx), len(idx)), "sweep_drop")
+
+    def sweep_solution_of(self, instance, n_vars=None):
+        """Model of an instance that already reported Sat, while the sweep is running."""
+        n_vars = self._n_vars if n_vars is None else n_vars
+        out = np.zeros(n_vars, dtype=np.int8)
+        self._check(self._L.mi355sat_sweep_model_of(self._h, instance, _p(out), n_vars), "sweep_solution_of")
+        return out
 
     def sweep_end(self):
         self._check(self._L.mi355sat_sweep_end(self._h), "sweep_end")
