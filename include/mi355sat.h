@@ -118,6 +118,10 @@ typedef struct mi355sat_stats_t {
 /* --- lifecycle (Default::default / Drop) --------------------------------- */
 mi355sat* mi355sat_new(const mi355sat_opts* opts);
 void mi355sat_free(mi355sat* s);
+/* mi355sat_free parks the handle's worker slabs (the one large device allocation: up to 147 GiB, 2-5 s of
+ * hipMalloc) for the next handle of the process on the same device - the refinement loop makes a fresh
+ * solver per bound (crates/repl/src/main.rs:295).  This returns the parked buffer to the driver. */
+void mi355sat_release_cached_memory(void);
 const char* mi355sat_signature(void);                 /* Solve::signature */
 /* sizeof(mi355sat_opts) (returned) and sizeof(mi355sat_stats_t) (*stats_size) of THIS build: a binding whose
  * mirror structs have other sizes was written against another header and must refuse to run. */

@@ -200,6 +200,58 @@ struct DevBuf {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// The worker slabs are by far the largest allocation (4096 x 37 MiB = 147 GiB at rect 64x64) and hipMalloc
+// of that size takes 2-5 s on MI355X (measured; 33 GB/s) - more than most solves of the refinement loop, which
+// makes a FRESH solver per bound (main.rs:295).  So a freed handle parks its slab buffer here, one per device,
+// and the next handle of the process takes it over if it is large enough.  mi355sat_release_cached_memory()
+// returns it to the driver.
+struct SlabCache {
+    std::mutex mu;
+    char* p[64] = {nullptr};
+    size_t bytes[64] = {0};
+};
+SlabCache g_slab_cache;
+
+struct SlabBuf {
+    char* p = nullptr;
+    size_t n = 0;        // bytes in use
+    size_t cap = 0;      // bytes allocated
+    int dev = 0;
+    static size_t cached_bytes(int dev) {
+        std::lock_guard<std::mutex> g(g_slab_cache.mu);
+        return dev >= 0 && dev < 64 ? g_slab_cache.bytes[dev] : 0;
+    }
+    void alloc(size_t bytes, int device) {
+        release();
+        dev = device;
+        if (!bytes) return;
+        {
+            std::lock_guard<std::mutex> g(g_slab_cache.mu);
+            if (dev >= 0 && dev < 64 && g_slab_cache.p[dev]) {
+                if (g_slab_cache.bytes[dev] >= bytes) { p = g_slab_cache.p[dev]; cap = g_slab_cache.bytes[dev]; }
+                else (void)hipFree(g_slab_cache.p[dev]);     // too small: make room before the larger request
+                g_slab_cache.p[dev] = nullptr;
+                g_slab_cache.bytes[dev] = 0;
+            }
+        }
+        if (!p) { HIPCHK(hipMalloc((void**)&p, bytes)); cap = bytes; }
+        n = bytes;
+    }
+    void release() {
+        if (p) {
+            std::lock_guard<std::mutex> g(g_slab_cache.mu);
+            if (dev >= 0 && dev < 64 && g_slab_cache.bytes[dev] < cap) {
+                if (g_slab_cache.p[dev]) (void)hipFree(g_slab_cache.p[dev]);
+                g_slab_cache.p[dev] = p;
+                g_slab_cache.bytes[dev] = cap;
+            } else (void)hipFree(p);
+        }
+        p = nullptr;
+        n = cap = 0;
+    }
+    ~SlabBuf() { release(); }
+};
+
 }  // namespace
 
 struct mi355sat {
@@ -228,7 +280,8 @@ struct mi355sat {
     DevBuf<ms_int2> d_tern_pairs;
     bool lds_val = false;                      // assignment staged in LDS (2 bits/var)
     uint32_t lds_val_bytes = 0;
-    DevBuf<char> d_template, d_slabs;
+    DevBuf<char> d_template;
+    SlabBuf d_slabs;
     DevBuf<MsState> d_states;
     DevBuf<int32_t> d_any_done, d_assump, d_script, d_proof;
     DevBuf<uint32_t> d_proof_len;
@@ -596,6 +649,7 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     // worker count limited by free HBM
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    free_b += SlabBuf::cached_bytes(s.device);   // a parked slab buffer of an earlier handle is ours to reuse
     uint64_t fit = (uint64_t)((double)free_b * 0.85) / (s.L.slab_bytes * 1ull);
     if (fit < 2) throw HipErr{"not enough device memory for one worker slab"};
     uint32_t W = (uint32_t)std::min<uint64_t>(want_workers, fit - 1);
@@ -603,7 +657,9 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.n_workers = W;
     s.d_template.alloc(s.L.slab_bytes);
     HIPCHK(hipMemcpyAsync(s.d_template.p, tmpl.data(), s.L.slab_bytes, hipMemcpyHostToDevice, s.stream));
-    s.d_slabs.alloc((size_t)W * s.L.slab_bytes);
+    const double t_alloc0 = now_s();
+    s.d_slabs.alloc((size_t)W * s.L.slab_bytes, s.device);
+    if (s.opts.verbose) fprintf(stderr, "[mi355sat] slab allocation %.1f GiB: %.3f s\n", (double)W * s.L.slab_bytes / 1073741824.0, now_s() - t_alloc0);
     s.d_states.alloc(W);
     s.d_any_done.alloc(1);
     // clause exchange: on unless switched off, whenever there is more than one worker and no proof is logged
@@ -1086,6 +1142,16 @@ extern "C" {
 uint64_t mi355sat_abi_sizes(uint64_t* stats_size) {
     if (stats_size) *stats_size = sizeof(mi355sat_stats_t);
     return sizeof(mi355sat_opts);
+}
+
+void mi355sat_release_cached_memory(void) {
+    std::lock_guard<std::mutex> g(g_slab_cache.mu);
+    for (int d = 0; d < 64; d++)
+        if (g_slab_cache.p[d]) {
+            if (hipSetDevice(d) == hipSuccess) (void)hipFree(g_slab_cache.p[d]);
+            g_slab_cache.p[d] = nullptr;
+            g_slab_cache.bytes[d] = 0;
+        }
 }
 
 const char* mi355sat_signature(void) { return "mi355sat 0.1 (HIP/gfx950 wave-parallel CDCL)"; }
