@@ -83,7 +83,8 @@ def main():
     workers = max(len(ks), args.workers // len(ks) * len(ks))
 
     solver = Mi355Sat(device=device_index, workers=workers, slice_ms=args.slice_ms, seed=1000 + rank,
-                      var_order=args.var_order, share=args.share)
+                      var_order=args.var_order, share=args.share,
+                      ramp=-1)   # throughput of the whole fleet is what is measured: no ramp-up phase
     solver.add_cnf(cnf.lits, cnf.offsets)
     solver.reserve(cnf.n_vars)
     solver.sweep_begin(assumption_sets)  # upload + replicate: everything resident in HBM from here on

@@ -84,6 +84,9 @@ typedef struct mi355sat_opts {
                                   that those meeting in clauses are neighbours (256-variable blobs grown breadth-first
                                   through the clauses).  Invisible at this interface: literals, models and proofs are
                                   always in the caller's numbering.  Measured on rect 64x64: no gain. */
+    int32_t ramp;              /* 0 = default (on): the first 100 ms of kernel time of a solve run 256 workers (one per
+                                  CU, each ~3x faster than one of 16), the next 300 ms 1024, then all - easy instances
+                                  are decided by one worker's few hundred conflicts; -1 = the whole fleet at once */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
 } mi355sat_opts;

@@ -237,8 +237,9 @@ def test_degenerate_inputs_on_device():
     s.close()
 
 
-@pytest.mark.parametrize("kw", [dict(share=-1), dict(share=0, share_lbd=4), dict(var_order=1), dict(rebalance=-1)],
-                         ids=["no-exchange", "exchange-lbd4", "locality-order", "no-rebalance"])
+@pytest.mark.parametrize("kw", [dict(share=-1), dict(share=0, share_lbd=4), dict(var_order=1), dict(rebalance=-1),
+                                dict(workers=2048), dict(workers=2048, ramp=-1)],
+                         ids=["no-exchange", "exchange-lbd4", "locality-order", "no-rebalance", "ramp-2048", "no-ramp-2048"])
 def test_exchange_order_and_rebalancing_never_change_an_answer(kw):
     """The learnt-clause exchange, the device's own variable numbering and the migration of workers
     are search strategy: verdicts equal the golden ones, models check against the caller's CNF."""
@@ -247,7 +248,7 @@ def test_exchange_order_and_rebalancing_never_change_an_answer(kw):
         grid = make_grid(terrain)
         enc = Encoding.encode(platform_defs(pset), grid)
         cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
-        s = Mi355Sat(workers=256, slice_ms=2, **kw)
+        s = Mi355Sat(**{"workers": 256, "slice_ms": 2, **kw})
         s.add_cnf(cnf.lits, cnf.offsets)
         r = s.solve()
         assert r.name.upper() == want, (terrain, pset, k)
@@ -306,14 +307,19 @@ def test_sweep_with_exchange_migration_and_withdrawn_instances_finds_the_cut():
     s.close()
 
 
-@pytest.mark.parametrize("terrain,pset,k0,kstar", [("rect16x16", "default", 40, 4), ("ex3", "default", 20, 1), ("ex2", "default", 12, 4)])
-def test_solver_loop_sweep_reaches_the_same_optimum_as_the_sequential_loop(terrain, pset, k0, kstar):
+@pytest.mark.parametrize("terrain,pset,k0,kstar,kw", [("rect16x16", "default", 40, 4, dict(workers=1024, slice_ms=2)),
+                                                      ("ex3", "default", 20, 1, dict(workers=1024, slice_ms=2)),
+                                                      ("ex2", "default", 12, 4, dict(workers=1024, slice_ms=2)),
+                                                      ("rect24x24", "default", 24, 9, dict())])
+def test_solver_loop_sweep_reaches_the_same_optimum_as_the_sequential_loop(terrain, pset, k0, kstar, kw):
+    """The last case runs with the default options long enough to leave the ramp-up: the fleet grows from one
+    worker per CU to the default 1024 in flight (grow_workers: slabs allocated on demand, running workers moved)."""
     from timberborn_support_solver_amd import solver_loop_sweep
     grid = make_grid(terrain)
     enc = Encoding.encode(platform_defs(pset), grid)
     lines = []
     hist = solver_loop_sweep(grid, enc, PlatformLimits({(1, 1): k0}), out=lines.append, time_limit=120,
-                             make_solver=lambda: Mi355Sat(workers=1024, slice_ms=2))
+                             make_solver=lambda: Mi355Sat(**kw))
     sat = [h for h in hist if h["result"] == SolverResult.Sat]
     assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == kstar - 1 and 1 <= len(sat) <= 2
     assert sat[-1]["count"] == kstar and all(h["valid"] for h in sat)

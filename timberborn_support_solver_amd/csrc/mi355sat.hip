@@ -46,8 +46,9 @@ struct HipErr { std::string msg; };
 // (affine permutation of the variables; worker group 0 keeps the canonical order).
 __global__ void ms_customize_kernel(MsLayout L, char* slabs, uint32_t n_workers, const int32_t* assump_data,
                                     const uint64_t* assump_off, const int32_t* script_data,
-                                    const uint64_t* script_off, uint32_t n_instances, uint64_t seed, int32_t park_from) {
-    const uint32_t wid = blockIdx.x;
+                                    const uint64_t* script_off, uint32_t n_instances, uint64_t seed, int32_t park_from,
+                                    uint32_t wid0) {
+    const uint32_t wid = blockIdx.x + wid0;   // workers [wid0, n_workers)
     if (wid >= n_workers) return;
     char* slab = slabs + (size_t)wid * L.slab_bytes;
     MsState* st = (MsState*)(slab + L.state);
@@ -295,6 +296,7 @@ struct mi355sat {
     MsShared sh{};
     MsLayout L{};
     uint32_t n_workers = 0;
+    uint32_t n_alloc = 0;                      // workers [0, n_alloc) have their slab (the rest is allocated on demand)
     uint64_t pool_init = 0;                    // watch-pool entries in use in the template
     // prepared formula facts
     bool trivially_unsat = false;
@@ -621,7 +623,8 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
 
 void set_error(mi355sat* s, const std::string& m) { s->err = m; }
 
-void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_t script_cap, uint32_t want_workers) {
+void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_t script_cap, uint32_t want_workers,
+                    uint32_t initial_workers = 0) {
     HIPCHK(hipSetDevice(s.device));
     std::vector<char> tmpl;
     build_layout_and_template(s, P, assump_cap, script_cap, tmpl);
@@ -657,9 +660,14 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.n_workers = W;
     s.d_template.alloc(s.L.slab_bytes);
     HIPCHK(hipMemcpyAsync(s.d_template.p, tmpl.data(), s.L.slab_bytes, hipMemcpyHostToDevice, s.stream));
+    // Slabs for `initial_workers` only (the ramp-up's first phase) unless a parked buffer already covers all of
+    // them: hipMalloc costs ~30 ms per GiB, and an easy instance never needs the rest (grow_workers).
+    uint32_t A = W;
+    if (initial_workers && initial_workers < W && SlabBuf::cached_bytes(s.device) < (size_t)W * s.L.slab_bytes) A = initial_workers;
+    s.n_alloc = A;
     const double t_alloc0 = now_s();
-    s.d_slabs.alloc((size_t)W * s.L.slab_bytes, s.device);
-    if (s.opts.verbose) fprintf(stderr, "[mi355sat] slab allocation %.1f GiB: %.3f s\n", (double)W * s.L.slab_bytes / 1073741824.0, now_s() - t_alloc0);
+    s.d_slabs.alloc((size_t)A * s.L.slab_bytes, s.device);
+    if (s.opts.verbose) fprintf(stderr, "[mi355sat] slab allocation %.1f GiB (%u of %u workers): %.3f s\n", (double)A * s.L.slab_bytes / 1073741824.0, A, W, now_s() - t_alloc0);
     s.d_states.alloc(W);
     s.d_any_done.alloc(1);
     // clause exchange: on unless switched off, whenever there is more than one worker and no proof is logged
@@ -679,14 +687,18 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
 }
 
 // Replicate the template into every worker slab (head + initial watch pool only).
-void reset_workers(mi355sat& s) {
+void replicate_template(mi355sat& s, uint32_t from, uint32_t to) {   // workers [from, to)
     const MsLayout& L = s.L;
     const size_t head = L.lc_lits;  // everything before the learnt literal store
-    const MsState* tst = nullptr;
-    (void)tst;
-    hipLaunchKernelGGL(ms_replicate_kernel, dim3(64, s.n_workers), dim3(256), 0, s.stream, (const char*)s.d_template.p,
-                       s.d_slabs.p, (uint64_t)L.slab_bytes, (uint64_t)head, (uint64_t)L.pool, (uint64_t)(8 * s.pool_init));
+    if (to <= from) return;
+    hipLaunchKernelGGL(ms_replicate_kernel, dim3(64, to - from), dim3(256), 0, s.stream, (const char*)s.d_template.p,
+                       s.d_slabs.p + (size_t)from * L.slab_bytes, (uint64_t)L.slab_bytes, (uint64_t)head, (uint64_t)L.pool,
+                       (uint64_t)(8 * s.pool_init));
     HIPCHK(hipGetLastError());
+}
+
+void reset_workers(mi355sat& s) {
+    replicate_template(s, 0, s.n_alloc);
     HIPCHK(hipMemsetAsync(s.d_any_done.p, 0, sizeof(int32_t), s.stream));
     if (s.share_slots) {
         HIPCHK(hipMemsetAsync(s.d_share_n.p, 0, sizeof(unsigned long long), s.stream));
@@ -706,19 +718,44 @@ void customize(mi355sat& s, const std::vector<int32_t>* assump, const std::vecto
         s.d_script.upload(script->empty() ? std::vector<int32_t>{0} : *script, s.stream);
         s.d_script_off.upload(*script_off, s.stream);
     }
-    hipLaunchKernelGGL(ms_customize_kernel, dim3(s.n_workers), dim3(256), 0, s.stream, s.L, s.d_slabs.p,
-                       s.n_workers, assump_off ? s.d_assump.p : nullptr, assump_off ? s.d_assump_off.p : nullptr,
+    hipLaunchKernelGGL(ms_customize_kernel, dim3(s.n_alloc), dim3(256), 0, s.stream, s.L, s.d_slabs.p,
+                       s.n_alloc, assump_off ? s.d_assump.p : nullptr, assump_off ? s.d_assump_off.p : nullptr,
                        script_off ? s.d_script.p : nullptr, script_off ? s.d_script_off.p : nullptr, n_instances,
-                       s.opts.seed, park_from);
+                       s.opts.seed, park_from, 0u);
     HIPCHK(hipGetLastError());
 }
 
-void gather_states(mi355sat& s, std::vector<MsState>& out) {
-    out.resize(s.n_workers);
-    hipLaunchKernelGGL(ms_gather_states_kernel, dim3((s.n_workers + 63) / 64), dim3(64), 0, s.stream, s.L,
-                       s.d_slabs.p, s.n_workers, s.d_states.p);
+// The search outlived the ramp-up's first phase: give the remaining workers their slabs.  The running workers'
+// slabs move into the full-size buffer (device-to-device copy), the new ones start from the template with the
+// assumption list of instance w % n_instances, as at the beginning.
+void grow_workers(mi355sat& s, uint32_t n_instances, uint32_t target) {
+    target = std::min(target, s.n_workers);
+    if (s.n_alloc >= target) return;
+    const uint32_t old = s.n_alloc;
+    const double t0 = now_s();
+    SlabBuf big;
+    big.alloc((size_t)target * s.L.slab_bytes, s.device);
+    HIPCHK(hipMemcpyAsync(big.p, s.d_slabs.p, (size_t)old * s.L.slab_bytes, hipMemcpyDeviceToDevice, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    std::swap(big.p, s.d_slabs.p); std::swap(big.n, s.d_slabs.n); std::swap(big.cap, s.d_slabs.cap); std::swap(big.dev, s.d_slabs.dev);
+    big.release();   // the small buffer (parked if nothing larger is)
+    s.n_alloc = target;
+    replicate_template(s, old, s.n_alloc);
+    hipLaunchKernelGGL(ms_customize_kernel, dim3(s.n_alloc - old), dim3(256), 0, s.stream, s.L, s.d_slabs.p, s.n_alloc,
+                       s.d_assump.p, s.d_assump_off.p, (const int32_t*)nullptr, (const uint64_t*)nullptr, n_instances, s.opts.seed,
+                       -1, old);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out.data(), s.d_states.p, sizeof(MsState) * s.n_workers, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    if (s.opts.verbose) fprintf(stderr, "[mi355sat] grew from %u to %u worker slabs (%.1f GiB): %.3f s\n", old, s.n_alloc,
+                                (double)s.n_alloc * s.L.slab_bytes / 1073741824.0, now_s() - t0);
+}
+
+void gather_states(mi355sat& s, std::vector<MsState>& out) {
+    out.assign(s.n_workers, MsState{});   // a worker without a slab yet: RUNNING, all counters zero
+    hipLaunchKernelGGL(ms_gather_states_kernel, dim3((s.n_alloc + 63) / 64), dim3(64), 0, s.stream, s.L,
+                       s.d_slabs.p, s.n_alloc, s.d_states.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out.data(), s.d_states.p, sizeof(MsState) * s.n_alloc, hipMemcpyDeviceToHost, s.stream));
     HIPCHK(hipStreamSynchronize(s.stream));
 }
 
@@ -764,9 +801,10 @@ void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_
 
 struct SliceResult { float ms; };
 
-SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_refuted = true) {
+SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_refuted = true, uint32_t active = 0) {
+    if (active == 0 || active > s.n_alloc) active = s.n_alloc;   // workers [0, active) run this slice
     MsParams prm{};
-    prm.n_workers = s.n_workers;
+    prm.n_workers = active;
     prm.slice_conflicts = s.opts.slice_conflicts > 0 ? (uint32_t)s.opts.slice_conflicts : 0xffffffffu;
     prm.slice_props = 0;
     // default: time-bounded slices (all workers stop together; no straggler tail), 20 ms
@@ -795,11 +833,11 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     const uint32_t dyn = s.lds_val ? s.lds_val_bytes : 0;
     HIPCHK(hipEventRecord(s.ev0, s.stream));
     if (mode == 0) {
-        if (s.lds_val) hipLaunchKernelGGL(ms_search_kernel<true>, dim3(s.n_workers), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
-        else hipLaunchKernelGGL(ms_search_kernel<false>, dim3(s.n_workers), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        if (s.lds_val) hipLaunchKernelGGL(ms_search_kernel<true>, dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        else hipLaunchKernelGGL(ms_search_kernel<false>, dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
     } else {
-        if (s.lds_val) hipLaunchKernelGGL(ms_bcp_kernel<true>, dim3(s.n_workers), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
-        else hipLaunchKernelGGL(ms_bcp_kernel<false>, dim3(s.n_workers), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        if (s.lds_val) hipLaunchKernelGGL(ms_bcp_kernel<true>, dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        else hipLaunchKernelGGL(ms_bcp_kernel<false>, dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.ev1, s.stream));
@@ -807,8 +845,8 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
         if ((++s.share_slices & 255) == 0)   // forget old signatures before the set fills up (a clause may then be passed on twice)
             HIPCHK(hipMemsetAsync(s.d_share_hash.p, 0, sizeof(unsigned long long) * s.share_hash_n, s.stream));
         HIPCHK(hipMemsetAsync(s.d_share_intake.p, 0, sizeof(uint32_t), s.stream));
-        hipLaunchKernelGGL(ms_share_collect_kernel, dim3((s.n_workers + 63) / 64), dim3(64), 0, s.stream, s.L, s.d_slabs.p,
-                           s.n_workers, s.d_share_pool.p, s.share_slots, s.d_share_n.p, s.d_share_hash.p, s.share_hash_n - 1,
+        hipLaunchKernelGGL(ms_share_collect_kernel, dim3((s.n_alloc + 63) / 64), dim3(64), 0, s.stream, s.L, s.d_slabs.p,
+                           s.n_alloc, s.d_share_pool.p, s.share_slots, s.d_share_n.p, s.d_share_hash.p, s.share_hash_n - 1,
                            s.d_share_intake.p, share_intake_cap);
         HIPCHK(hipGetLastError());
     }
@@ -858,6 +896,7 @@ struct Sweep {
     std::vector<int32_t> base_assump;            // internal literals
     std::vector<uint64_t> base_off;
     uint64_t n_moved = 0;
+    float ramp_ms = 0;                           // kernel time of this sweep so far
     uint32_t decided = 0;
     bool stop_at_first = false;
     bool active = false;
@@ -887,6 +926,7 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     sw.winner.assign(n_instances, -1);
     sw.dropped.assign(n_instances, 0);
     sw.n_moved = 0;
+    sw.ramp_ms = 0;
     if (P.unsat) {
         std::fill(sw.results.begin(), sw.results.end(), MI355SAT_UNSAT);
         sw.decided = n_instances;
@@ -919,9 +959,11 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     for (uint32_t i = 0; i < n_instances; i++)
         max_assumps = std::max<uint32_t>(max_assumps, (uint32_t)(assump_off[i + 1] - assump_off[i]));
     const uint32_t assump_cap = sw.split ? max_assumps + 512 : max_assumps;
-    upload_formula(s, P, assump_cap, 0, want);
+    const uint32_t initial = (s.opts.ramp >= 0 && !sw.split) ? std::max(256u, n_instances) / n_instances * n_instances : 0;
+    upload_formula(s, P, assump_cap, 0, want, initial);
     if (s.n_workers < n_instances) throw HipErr{"not enough device memory for one worker per instance"};
     s.n_workers = s.n_workers / n_instances * n_instances;
+    s.n_alloc = std::min(s.n_alloc, s.n_workers);
     reset_workers(s);
     customize(s, &a_int, &assump_off, nullptr, nullptr, n_instances, sw.split ? (int32_t)n_instances : -1);
     HIPCHK(hipStreamSynchronize(s.stream));
@@ -1012,9 +1054,9 @@ inline bool inst_open(const Sweep& sw, uint32_t inst) { return sw.results[inst] 
 // the open instances with the fewest workers.  They keep their learnt clauses (consequences of the
 // formula alone) and only swap their assumption list; the worker holding a SAT instance's model stays.
 void rebalance_workers(mi355sat& s, Sweep& sw) {
-    const uint32_t W = s.n_workers, n_instances = sw.n_instances;
+    const uint32_t n_instances = sw.n_instances;
     std::vector<uint32_t> cnt(n_instances, 0), movable;
-    for (uint32_t w = 0; w < W; w++) {
+    for (uint32_t w = 0; w < s.n_alloc; w++) {   // (a worker without a slab yet is picked up after grow_workers)
         const uint32_t inst = (uint32_t)sw.w_inst[w];
         const int st = sw.sts[w].status;
         if (inst_open(sw, inst)) { if (st == MS_ST_RUNNING) cnt[inst]++; continue; }
@@ -1059,7 +1101,19 @@ void rebalance_workers(mi355sat& s, Sweep& sw) {
 int sweep_step(mi355sat& s, Sweep& sw) {
     if (!sw.active) return 0;
     const uint32_t n_instances = sw.n_instances;
-    launch_slice(s, 0, /*stop_on_any=*/n_instances == 1 || sw.stop_at_first, /*done_on_refuted=*/!sw.split);
+    // Ramp-up: a worker alone on its CU runs ~3x faster than one of 16, and an easy instance is decided by ONE
+    // worker's few hundred conflicts - so the first 100 ms of kernel time go to one worker per CU, the next
+    // 300 ms to four, and only a search that is still open after that gets the whole fleet.  (Measured: rect
+    // 32x32 k=120 0.167 -> 0.088 s; 250 / 1000 ms thresholds gain nothing more at 64x64 - a worker there is bound
+    // by DRAM latency even when alone - and delay the rect 24x24 ladder by 0.5-1 s.)
+    uint32_t active = s.n_workers;
+    if (s.opts.ramp >= 0 && !sw.split) {
+        const uint32_t want = sw.ramp_ms < 100.f ? 256u : (sw.ramp_ms < 400.f ? 1024u : s.n_workers);
+        active = std::min(s.n_workers, std::max(want, n_instances) / n_instances * n_instances);
+    }
+    if (active > s.n_alloc) grow_workers(s, n_instances, active);
+    SliceResult sr = launch_slice(s, 0, /*stop_on_any=*/n_instances == 1 || sw.stop_at_first, /*done_on_refuted=*/!sw.split, active);
+    sw.ramp_ms += sr.ms;
     gather_states(s, sw.sts);
     int rc = 0;
     uint64_t confl = 0;
