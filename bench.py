@@ -82,7 +82,11 @@ def main():
     assumption_sets = [([-int(outs[k])] if k < args.k_hi else []) for k in ks]
     workers = max(len(ks), args.workers // len(ks) * len(ks))
 
-    solver = Mi355Sat(device=device_index, workers=workers, slice_ms=args.slice_ms, seed=1000 + rank,
+    lib_override = None
+    if os.environ.get("BENCH_LIB"):   # A/B of diagnostic builds of the same library (e.g. -DMS_SPECULATE=0)
+        import ctypes
+        lib_override = ctypes.CDLL(os.path.abspath(os.environ["BENCH_LIB"]))
+    solver = Mi355Sat(device=device_index, workers=workers, slice_ms=args.slice_ms, seed=1000 + rank, _lib_override=lib_override,
                       var_order=args.var_order, share=args.share,
                       ramp=-1)   # throughput of the whole fleet is what is measured: no ramp-up phase
     solver.add_cnf(cnf.lits, cnf.offsets)

@@ -59,6 +59,9 @@ typedef unsigned long long u64;
 #endif
 enum { PF_OFF = 0, PF_BIN, PF_TERN, PF_LONG, PF_CLOSE, PF_ANALYZE, PF_BACKJUMP, PF_DECIDE, PF_REDUCE, PF_N };
 
+#ifndef MS_SPECULATE
+#define MS_SPECULATE 1   // load a watcher's clause header and watched pair together with its blocker's value
+#endif
 #define DEV __device__ __forceinline__
 // cold paths are real calls: keeps them out of the hot loop's register allocation
 #define DEV_COLD __device__ __noinline__
@@ -308,10 +311,16 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
     R.wt = wt; R.live = live; R.keep = live; R.want = false; R.cf = false; R.deferred = false; R.imp = 0;
     bool scanning = false, need_tail = false;
     int other = 0, vo = MS_VAL_TRUE, r = -1;
-    const int size = (int)ch.size;
+    int size = (int)ch.size;
     const int32_t* cl = ((uint32_t)wt.x < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + ch.start;
     uint32_t nl = 0;
     if (live && vbl != MS_VAL_TRUE) {
+#if !MS_SPECULATE
+        ww = WKA(int2, wl)[wt.x];            // only for watchers whose blocker is not true (one more round trip,
+        ch = clause_hdr_of(w, sh, L, wt.x);  // two lines less per satisfied watcher)
+        size = (int)ch.size;
+        cl = ((uint32_t)wt.x < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + ch.start;
+#endif
         other = (ww.x == fl) ? ww.y : ww.x;
         // the other watch and the first MS_LANE_SCAN literals (16-byte loads) + their values, issued together
         int ls[MS_LANE_SCAN], vs[MS_LANE_SCAN];
@@ -455,8 +464,13 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int vb = act_t ? lit_value<LV>(w, sh, L, pr0.x) : MS_VAL_TRUE;
         const int vc = act_t ? lit_value<LV>(w, sh, L, pr0.y) : MS_VAL_TRUE;
         const int vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
+#if MS_SPECULATE
         const int2 ww0 = live0 ? wl[wt0.x] : make_int2(0, 0);
         const MsClauseHdr ch0 = live0 ? clause_hdr_of(w, sh, L, wt0.x) : MsClauseHdr{0, 0};
+#else
+        const int2 ww0 = make_int2(0, 0);
+        const MsClauseHdr ch0 = MsClauseHdr{0, 0};
+#endif
         PROF_MARK(PF_OFF);
         // evaluate binary + ternary entries on the snapshot
         const bool cf_b = vq == MS_VAL_FALSE, want_b = vq == MS_VAL_UNDEF;
@@ -579,8 +593,13 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 const int2 wt = act ? pool[wb_l + i] : make_int2(-1, 0);
                 const bool live = act && wt.x >= 0;
                 const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
+#if MS_SPECULATE
                 const int2 ww = live ? wl[wt.x] : make_int2(0, 0);
                 const MsClauseHdr ch = live ? clause_hdr_of(w, sh, L, wt.x) : MsClauseHdr{0, 0};
+#else
+                const int2 ww = make_int2(0, 0);
+                const MsClauseHdr ch = MsClauseHdr{0, 0};
+#endif
                 w.c_watch += (uint32_t)popc64(ballot(live));
                 LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, ch, fl_l, gl);
                 w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
