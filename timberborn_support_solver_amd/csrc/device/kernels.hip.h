@@ -59,6 +59,12 @@ typedef unsigned long long u64;
 #endif
 enum { PF_OFF = 0, PF_BIN, PF_TERN, PF_LONG, PF_CLOSE, PF_ANALYZE, PF_BACKJUMP, PF_DECIDE, PF_REDUCE, PF_N };
 
+#ifndef MS_MINIMIZE
+#define MS_MINIMIZE 1    // learnt-clause minimisation: 1 local (one reason deep), 2 recursive (lit_redundant)
+#endif
+#ifndef MS_BUMP_MODE
+#define MS_BUMP_MODE 0   // decision-queue bumping after a conflict, see analyze()
+#endif
 #ifndef MS_SPECULATE
 #define MS_SPECULATE 1   // load a watcher's clause header and watched pair together with its blocker's value
 #endif
@@ -724,6 +730,83 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
 // ---- conflict analysis (first UIP) -----------------------------------------
 struct Learnt { int n, bt_level; uint32_t lbd; };
 
+// ---- recursive clause minimisation (MiniSat's litRedundant, one learnt literal per lane) ----------
+// q (false, with a reason) can be dropped from the learnt clause if every other literal of its reason is in
+// the clause, fixed at level 0, or itself implied by the clause in this sense.  Each lane walks the
+// implication graph of its own literal depth-first with a small private stack; what it proves about a
+// variable either way is memoised in the variable's record under this conflict's stamp, so lanes profit
+// from each other (the facts do not depend on who finds them; reasons point backwards on the trail, so
+// there are no cycles).  Literals at decision levels the clause does not touch cannot be implied by it
+// (abstract-level filter).  Too deep a walk gives up (keeps the literal).
+#ifndef MS_MIN_BUDGET
+#define MS_MIN_BUDGET 64     // reason literals one lane may inspect for its clause literal
+#endif
+#define MS_MIN_DEPTH 16
+struct MinFrame {
+    int var, n, idx;
+    int l0, l1, l2;          // binary / ternary reason: its literals
+    const int32_t* cl;       // long reason: its literal array
+};
+DEV void min_open(const Wk& w, const MsShared& sh, const MsLayout& L, MinFrame& f, int var, int r) {
+    f.var = var; f.idx = 0; f.cl = nullptr; f.l0 = f.l1 = f.l2 = 0;
+    if (r >= 0) {
+        const MsClauseHdr ch = clause_hdr_of(w, sh, L, r);
+        f.n = (int)ch.size;
+        f.cl = ((uint32_t)r < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + ch.start;
+    } else if (MS_IS_TERN_REASON(r)) {
+        const int e = MS_TERN_REASON_ENTRY(r);
+        const int2 pr = ((const int2*)sh.tern_pairs)[e];
+        f.n = 3; f.l0 = sh.tern_owner[e] ^ 1; f.l1 = pr.x; f.l2 = pr.y;
+    } else {
+        f.n = 1; f.l0 = MS_BIN_REASON_LIT(r);
+    }
+}
+DEV bool lit_redundant(Wk& w, const MsShared& sh, const MsLayout& L, int q, uint32_t abs_levels, uint32_t stamp) {
+    MsVarRec* vrec = VREC;
+    MinFrame st[MS_MIN_DEPTH];
+    int sp = 0, budget = MS_MIN_BUDGET;
+    {
+        const int r = vrec[q >> 1].reason;
+        if (r == MS_REASON_NONE) return false;
+        min_open(w, sh, L, st[0], q >> 1, r);
+    }
+    for (;;) {
+        MinFrame& f = st[sp];
+        bool failed = false, descended = false;
+        while (f.idx < f.n) {
+            const int k = f.idx++;
+            const int y = (f.cl ? f.cl[k] : (k == 0 ? f.l0 : (k == 1 ? f.l1 : f.l2))) >> 1;
+            if (y == f.var) continue;
+            const MsVarRec yr = vrec[y];
+            if (yr.level == 0 || yr.seen) continue;                       // fixed, or in the clause
+            if ((uint32_t)(yr.mstamp >> 2) == stamp) {                    // settled earlier in this conflict
+                if ((yr.mstamp & 3) == 2) continue;
+                failed = true;
+                break;
+            }
+            if (yr.reason == MS_REASON_NONE || !((abs_levels >> (yr.level & 31)) & 1u)) {
+                vrec[y].mstamp = (uint16_t)(stamp << 2 | 3u);
+                failed = true;
+                break;
+            }
+            if (sp + 1 == MS_MIN_DEPTH || --budget <= 0) { failed = true; break; }   // give up: nothing learnt about y
+            sp++;
+            min_open(w, sh, L, st[sp], y, yr.reason);
+            descended = true;
+            break;
+        }
+        if (failed) {   // every variable on the path needs a literal the clause does not imply
+            if (budget > 0 && sp + 1 < MS_MIN_DEPTH)
+                for (int i = 1; i <= sp; i++) vrec[st[i].var].mstamp = (uint16_t)(stamp << 2 | 3u);
+            return false;
+        }
+        if (descended) continue;
+        if (sp == 0) return true;
+        vrec[f.var].mstamp = (uint16_t)(stamp << 2 | 2u);
+        sp--;
+    }
+}
+
 DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, MsVarRec* vrec, int32_t* toclear, int32_t* learnt_buf, bool act, int q, int dl,
                        int& path_c, int& n_out, int& n_clear) {
     int v = q >> 1;
@@ -745,7 +828,7 @@ DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, MsVarRec* v
     path_c += popc64(cm);
 }
 
-DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
+DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp) {
     MsVarRec* vrec = VREC;
     int32_t* toclear = WK_PTR(int32_t, w, L, toclear);
     int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
@@ -805,6 +888,29 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
     wave_fence();
     if (w.lane == 0) learnt_buf[0] = p ^ 1;
     wave_fence();
+#if MS_MINIMIZE == 2
+    // ---- recursive minimisation (see lit_redundant).  Measured on MI355X: learnt clauses 150 -> 65 literals on
+    // the rect 20/24 rungs, but no consistent gain in conflicts to a verdict there and 11 % fewer propagations/s
+    // on the 64x64 sweep (8 % with MS_MIN_BUDGET=8) - so the default stays the one-reason-deep version below.
+    if (stamp == 0)   // the 14-bit stamp wrapped: forget every memo
+        for (uint32_t v = (uint32_t)w.lane; v < sh.n_vars; v += MS_WAVE) vrec[v].mstamp = 0;
+    uint32_t abs_levels = 0;
+    for (int i = 1 + w.lane; i < n_out; i += MS_WAVE) abs_levels |= 1u << (VREC[learnt_buf[i] >> 1].level & 31);
+    for (int o = 32; o > 0; o >>= 1) abs_levels |= (uint32_t)__shfl_xor((int)abs_levels, o, 64);
+    wave_fence();
+    int j = 1;
+    for (int i0 = 1; i0 < n_out; i0 += MS_WAVE) {
+        int i = i0 + w.lane;
+        bool act = i < n_out, keep = act;
+        int q = act ? learnt_buf[i] : 0;
+        if (act) keep = !lit_redundant(w, sh, L, q, abs_levels, stamp);
+        u64 km = ballot(keep);
+        wave_fence();
+        if (keep) learnt_buf[j + popc64(km & lanemask_lt(w.lane))] = q;
+        j += popc64(km);
+        wave_fence();
+    }
+#else
     // ---- local minimisation: drop a literal whose reason's other literals are all seen / level 0
     int j = 1;
     for (int i0 = 1; i0 < n_out; i0 += MS_WAVE) {
@@ -846,6 +952,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
         j += popc64(km);
         wave_fence();
     }
+#endif
     n_out = j;
     // ---- backjump level = max level among learnt_buf[1..), moved to position 1
     int bt = 0;
@@ -891,18 +998,52 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L) {
         }
         w.lvl_stamp_ctr = nb;
     }
-    // ---- clear marks and bump the analysed variables to the front of the queue
+    // ---- clear marks and bump variables to the front of the queue (MS_BUMP_MODE: which, in what order)
     if (w.vm_end + n_clear > (int)L.vm_cap) vm_compact(w, sh, L);
     {
         int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
+#if MS_BUMP_MODE == 2
+        // only the variables of the learnt clause, the asserting literal last (= first to be decided)
+        for (int i = w.lane; i < n_clear; i += MS_WAVE) vrec[toclear[i]].seen = 0;
+        wave_fence();
+        for (int i = w.lane; i < n_out; i += MS_WAVE) {
+            int v = learnt_buf[i] >> 1;
+            vm_order[w.vm_end + (n_out - 1 - i)] = v;
+            vrec[v].vm_pos = w.vm_end + (n_out - 1 - i);
+        }
+        w.vm_end += n_out;
+#elif MS_BUMP_MODE == 3
+        // every analysed variable, keeping their previous relative order (rank by old queue position)
+        uint32_t* key = WK_PTR(uint32_t, w, L, remap);   // scratch outside reduce_db
+        const bool ranked = n_clear <= 1024 && (uint32_t)n_clear <= L.learnt_cap;
+        if (ranked) {
+            for (int i = w.lane; i < n_clear; i += MS_WAVE) key[i] = (uint32_t)vrec[toclear[i]].vm_pos;
+            wave_fence();
+        }
         for (int i = w.lane; i < n_clear; i += MS_WAVE) {
             int v = toclear[i];
+            int r = i;
+            if (ranked) {
+                const uint32_t ki = key[i];
+                r = 0;
+                for (int j = 0; j < n_clear; j++) r += key[j] < ki;
+            }
             vrec[v].seen = 0;
-            vm_order[w.vm_end + i] = v;
-            vrec[v].vm_pos = w.vm_end + i;
+            vm_order[w.vm_end + r] = v;
+            vrec[v].vm_pos = w.vm_end + r;
         }
+        w.vm_end += n_clear;
+#else
+        for (int i = w.lane; i < n_clear; i += MS_WAVE) {
+            int v = toclear[i];
+            const int d = MS_BUMP_MODE == 1 ? n_clear - 1 - i : i;   // 0: in the order analysis met them, 1: reversed
+            vrec[v].seen = 0;
+            vm_order[w.vm_end + d] = v;
+            vrec[v].vm_pos = w.vm_end + d;
+        }
+        w.vm_end += n_clear;
+#endif
     }
-    w.vm_end += n_clear;
     wave_fence();
     return Learnt{n_out, bt, lbd};
 }
@@ -1236,7 +1377,7 @@ DEV_COLD bool on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     if (ls.conflicts > 10000 && ls.lbdq_n == MS_LBDQ && (double)w.trail_n > 1.4 * ls.trail_avg) {
         ls.lbdq_n = 0; ls.lbdq_i = 0; ls.lbdq_sum = 0;
     }
-    Learnt lr = analyze(w, sh, L);
+    Learnt lr = analyze(w, sh, L, (uint32_t)(ls.conflicts & 0x3fffu));
     PROF_MARK(PF_ANALYZE);
     if (w.status != MS_ST_RUNNING) return false;
     const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);

@@ -73,7 +73,8 @@ struct MsLitHdr { uint32_t bin_off, bin_n, tern_off, tern_n; };
 struct MsWatchHdr { uint32_t base, size, cap, pad; };
 // Per-variable record: everything BCP, backtracking and analysis touch for one variable sits in ONE
 // 16-byte slot (one 64-byte line per assignment instead of five).
-struct MsVarRec { int32_t level, reason, vm_pos; uint8_t phase, seen, pad0, pad1; };
+// mstamp: memo of clause minimisation, (conflict number & 0x3fff) << 2 | state (2 = implied by the clause, 3 = not)
+struct MsVarRec { int32_t level, reason, vm_pos; uint8_t phase, seen; uint16_t mstamp; };
 // Long / learnt clause header: literals start 16-byte aligned (4 literals) so that a lane reads 4 at a time.
 struct MsClauseHdr { uint32_t start, size; };
 
