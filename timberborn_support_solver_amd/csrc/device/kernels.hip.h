@@ -180,8 +180,7 @@ DEV void enqueue_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int lit, 
     if (w.lane == 0) {
         int v = lit >> 1;
         asg_set<LV>(w, sh, L, lit);
-        VREC[v].level = w.n_levels;
-        VREC[v].reason = reason;
+        *(MsVarHead*)&VREC[v] = MsVarHead{w.n_levels, reason, (uint32_t)(lit & 1)};
         WKA(int32_t, trail)[w.trail_n] = lit;
         w.ring[w.trail_n & (MS_LDS_RING - 1)] = lit;
     }
@@ -224,8 +223,7 @@ DEV void assign_winners(Wk& w, const MsShared& sh, const MsLayout& L, bool won, 
         const int v = q >> 1;
         const int t = w.trail_n + popc64(wm & lanemask_lt(w.lane));
         asg_set<LV>(w, sh, L, q);
-        VREC[v].level = w.n_levels;
-        VREC[v].reason = reason;
+        *(MsVarHead*)&VREC[v] = MsVarHead{w.n_levels, reason, (uint32_t)(q & 1)};
         WKA(int32_t, trail)[t] = q;
         w.ring[t & (MS_LDS_RING - 1)] = q;
     }
@@ -659,8 +657,7 @@ DEV void cancel_until(Wk& w, const MsShared& sh, const MsLayout& L, int lvl) {
     for (int i = lim + w.lane; i < w.trail_n; i += MS_WAVE) {
         int l = WKA(int32_t, trail)[i];
         int v = l >> 1;
-        asg_clear<LV>(w, sh, L, v);
-        vrec[v].phase = (uint8_t)(l & 1);
+        asg_clear<LV>(w, sh, L, v);   // (the saved phase was written with the assignment)
         maxpos = max(maxpos, vrec[v].vm_pos);
     }
     maxpos = wave_max(maxpos);

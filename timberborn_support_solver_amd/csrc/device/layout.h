@@ -74,7 +74,10 @@ struct MsWatchHdr { uint32_t base, size, cap, pad; };
 // Per-variable record: everything BCP, backtracking and analysis touch for one variable sits in ONE
 // 16-byte slot (one 64-byte line per assignment instead of five).
 // mstamp: memo of clause minimisation, (conflict number & 0x3fff) << 2 | state (2 = implied by the clause, 3 = not)
-struct MsVarRec { int32_t level, reason, vm_pos; uint8_t phase, seen; uint16_t mstamp; };
+// The first 12 bytes are written by ONE store when the variable is assigned (phase = its polarity now, which is
+// what phase saving would record at unassignment; seen and mstamp are 0 then), so backtracking writes nothing here.
+struct MsVarRec { int32_t level, reason; uint8_t phase, seen; uint16_t mstamp; int32_t vm_pos; };
+struct MsVarHead { int32_t level, reason; uint32_t phase_seen_mstamp; };
 // Long / learnt clause header: literals start 16-byte aligned (4 literals) so that a lane reads 4 at a time.
 struct MsClauseHdr { uint32_t start, size; };
 

@@ -600,7 +600,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     int32_t* vm_order = (int32_t*)(T + L.vm_order);
     for (uint32_t e = 0; e < nv; e++) {   // initial decision order: the caller's numbering, highest first
         const uint32_t v = P.perm[e];
-        vrec[v] = MsVarRec{0, MS_REASON_NONE, (int32_t)(nv - 1 - e), /*phase=*/1, /*seen=*/0, /*mstamp=*/0};
+        vrec[v] = MsVarRec{0, MS_REASON_NONE, /*phase=*/1, /*seen=*/0, /*mstamp=*/0, (int32_t)(nv - 1 - e)};
         vm_order[nv - 1 - e] = (int32_t)v;
     }
     int32_t* trail = (int32_t*)(T + L.trail);
