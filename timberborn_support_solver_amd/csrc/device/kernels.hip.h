@@ -652,16 +652,15 @@ template <bool LV>
 DEV void cancel_until(Wk& w, const MsShared& sh, const MsLayout& L, int lvl) {
     if (w.n_levels <= lvl) return;
     const int lim = uni(WK_PTR(int32_t, w, L, trail_lim)[lvl]);
-    MsVarRec* vrec = VREC;
-    int maxpos = -1;
     for (int i = lim + w.lane; i < w.trail_n; i += MS_WAVE) {
-        int l = WKA(int32_t, trail)[i];
-        int v = l >> 1;
-        asg_clear<LV>(w, sh, L, v);   // (the saved phase was written with the assignment)
-        maxpos = max(maxpos, vrec[v].vm_pos);
+        const int l = WKA(int32_t, trail)[i];
+        asg_clear<LV>(w, sh, L, l >> 1);   // (the saved phase was written with the assignment)
     }
-    maxpos = wave_max(maxpos);
-    if (maxpos > w.vm_search) w.vm_search = maxpos;
+    // Decision queue: "every live entry above vm_search is assigned" holds trivially for the front of the
+    // queue.  The exact bound (the highest queue position among the variables just unassigned) would cost one
+    // random variable-record line per backtracked literal; starting the next search at the front instead only
+    // makes pick_branch_var skip the few analysed variables that stay assigned (they were just bumped there).
+    w.vm_search = w.vm_end - 1;
     w.trail_n = lim;
     w.qhead = lim;
     w.n_levels = lvl;
