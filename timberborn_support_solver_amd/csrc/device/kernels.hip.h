@@ -380,8 +380,8 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
             WKA(int2, wl)[wt.x] = make_int2(other, r);
             const int t = r ^ 1;
             const uint32_t pos = atomicAdd(&whdr[t].size, 1u);
-            const MsWatchHdr th = whdr[t];
-            if (pos < th.cap) WKA(int2, pool)[th.base + pos] = R.wt;
+            const uint32_t tbase = whdr[t].base, tcap = whdr[t].cap;
+            if (pos < tcap) WKA(int2, pool)[tbase + pos] = R.wt;
             else {
                 uint32_t o = atomicAdd((uint32_t*)w.ov_cnt, 1u);
                 int32_t* ov = WK_PTR(int32_t, w, L, overflow);
@@ -444,10 +444,9 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int qbase = w.qhead;
         const int idx = qbase + g;
         const int p = (idx >= w.ring_lo) ? w.ring[idx & (MS_LDS_RING - 1)] : trail[idx];
-        const MsLitHdr lh = sh.lit_hdr[p];
-        const MsWatchHdr wh = whdr[p];
+        const MsWatchHdr wh = whdr[p];   // watch list + binary / ternary list headers: one line
         const int fl = p ^ 1;
-        const uint32_t b0 = lh.bin_off, nb = lh.bin_n, t0 = lh.tern_off, nt = lh.tern_n;
+        const uint32_t b0 = wh.bin_off, nb = wh.bin_n, t0 = wh.tern_off, nt = wh.tern_n;
         const uint32_t wb = wh.base;
         const int n = (int)wh.size;
         // round trip 1: the first chunk of all three lists
@@ -1074,7 +1073,7 @@ DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
             if (w.lane >= o) incl += x;
         }
         wave_fence();
-        if (t < nlist) whdr[t] = MsWatchHdr{run + incl - cap, 0, cap, 0};
+        if (t < nlist) { whdr[t].base = run + incl - cap; whdr[t].size = 0; whdr[t].cap = cap; }
         run += (uint32_t)bcast((int)incl, 63);
     }
     if (run > L.pool_cap) { w.status = MS_ST_ERR_POOL; return; }

@@ -69,8 +69,10 @@ enum {
 struct ms_int2 { int32_t x, y; };
 // Per-literal list header of the shared CSRs: ONE 16-byte load per dequeued literal.
 struct MsLitHdr { uint32_t bin_off, bin_n, tern_off, tern_n; };
-// Per-literal header of the private watch list: ONE 16-byte load; `size` is the atomic push counter.
-struct MsWatchHdr { uint32_t base, size, cap, pad; };
+// Per-literal header, private: the watch list (`size` is the atomic push counter) AND a copy of the literal's
+// immutable binary / ternary list header, so that a dequeued literal costs ONE 32-byte access to one line
+// instead of a private and a shared one (+16 B x 2 x n_vars per worker: 3 MB of 37 at rect 64x64).
+struct MsWatchHdr { uint32_t base, size, cap, pad; uint32_t bin_off, bin_n, tern_off, tern_n; };
 // Per-variable record: everything BCP, backtracking and analysis touch for one variable sits in ONE
 // 16-byte slot (one 64-byte line per assignment instead of five).
 // mstamp: memo of clause minimisation, (conflict number & 0x3fff) << 2 | state (2 = implied by the clause, 3 = not)
@@ -87,7 +89,6 @@ struct MsShared {
     uint32_t n_orig;               // long (>= 4 literal) original clauses, cref 0..n_orig-1
     const MsClauseHdr* cl_hdr;     // n_orig headers into cl_lits
     const int32_t* cl_lits;        // literals of the long original clauses (each clause 16-byte aligned)
-    const MsLitHdr* lit_hdr;       // 2*n_vars: where literal p's binary / ternary lists are
     const int32_t* bin_lits;       // implied literals q  (clause  ~p | q) of p being TRUE
     const ms_int2* tern_pairs;     // the other two literals (b, c) of clause (~p | b | c)
     const int32_t* tern_owner;     // per entry: the literal p whose list it is in (conflict analysis)
@@ -104,7 +105,8 @@ struct MsLayout {
     uint64_t trail_lim;   // int32  [n_vars+1]
     uint64_t vm_order;    // int32  [vm_cap]   move-to-front queue as an append-only array
     uint64_t wl;          // int2   [n_orig + learnt_cap]  the two watched literals per clause
-    uint64_t whdr;        // MsWatchHdr [2*n_vars]  the literal's watch list: slot in pool, size, capacity
+    uint64_t whdr;        // MsWatchHdr [2*n_vars]  the literal's watch list (slot in pool, size, capacity) + where its
+                          //        binary / ternary lists are in the shared CSRs
     uint64_t pool;        // int2   [pool_cap]  watcher = (cref, blocker); cref < 0 = tombstone
     uint64_t lc_hdr;      // MsClauseHdr [learnt_cap]
     uint64_t lc_lbd;      // uint32 [learnt_cap]  lbd | used<<31
