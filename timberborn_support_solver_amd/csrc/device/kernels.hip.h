@@ -157,15 +157,9 @@ DEV void asg_clear(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
 }
 
 DEV void clause_range(const Wk& w, const MsShared& sh, const MsLayout& L, int c, const int32_t*& lits, int& size) {
-    if ((uint32_t)c < sh.n_orig) {
-        const MsClauseHdr h = sh.cl_hdr[c];
-        lits = sh.cl_lits + h.start;
-        size = (int)h.size;
-    } else {
-        const MsClauseHdr h = WKA(MsClauseHdr, lc_hdr)[(uint32_t)c - sh.n_orig];
-        lits = WKA(int32_t, lc_lits) + h.start;
-        size = (int)h.size;
-    }
+    const MsClauseRec h = WKA(MsClauseRec, wl)[c];
+    lits = ((uint32_t)c < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + h.start;
+    size = (int)h.size;
 }
 
 // ---- trail -------------------------------------------------------------
@@ -301,7 +295,8 @@ struct LongRes {
 };
 
 DEV MsClauseHdr clause_hdr_of(const Wk& w, const MsShared& sh, const MsLayout& L, int c) {
-    return (uint32_t)c < sh.n_orig ? sh.cl_hdr[c] : WKA(MsClauseHdr, lc_hdr)[(uint32_t)c - sh.n_orig];
+    const MsClauseRec h = WKA(MsClauseRec, wl)[c];
+    return MsClauseHdr{h.start, h.size};
 }
 
 // Visit watcher `wt` of the false literal `fl`.  vbl / ww / ch are the blocker's value, the clause's
@@ -320,8 +315,11 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
     uint32_t nl = 0;
     if (live && vbl != MS_VAL_TRUE) {
 #if !MS_SPECULATE
-        ww = WKA(int2, wl)[wt.x];            // only for watchers whose blocker is not true (one more round trip,
-        ch = clause_hdr_of(w, sh, L, wt.x);  // two lines less per satisfied watcher)
+        {   // only for watchers whose blocker is not true (one more round trip, one line less per satisfied watcher)
+            const MsClauseRec cr = WKA(MsClauseRec, wl)[wt.x];
+            ww = make_int2(cr.w0, cr.w1);
+            ch = MsClauseHdr{cr.start, cr.size};
+        }
         size = (int)ch.size;
         cl = ((uint32_t)wt.x < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + ch.start;
 #endif
@@ -377,7 +375,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
     if (scanning) {
         if (r >= 0) {
             MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
-            WKA(int2, wl)[wt.x] = make_int2(other, r);
+            *(int2*)&WKA(MsClauseRec, wl)[wt.x] = make_int2(other, r);
             const int t = r ^ 1;
             const uint32_t pos = atomicAdd(&whdr[t].size, 1u);
             const uint32_t tbase = whdr[t].base, tcap = whdr[t].cap;
@@ -430,7 +428,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
     w.confl_kind = 0;
     MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
     int2* pool = WKA(int2, pool);
-    const int2* wl = WKA(int2, wl);
+    const MsClauseRec* wl = WKA(MsClauseRec, wl);
     const int32_t* trail = WKA(int32_t, trail);
     while (w.qhead < w.trail_n && w.status == MS_ST_RUNNING) {
         PROF_DECL
@@ -468,8 +466,9 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int vc = act_t ? lit_value<LV>(w, sh, L, pr0.y) : MS_VAL_TRUE;
         const int vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
 #if MS_SPECULATE
-        const int2 ww0 = live0 ? wl[wt0.x] : make_int2(0, 0);
-        const MsClauseHdr ch0 = live0 ? clause_hdr_of(w, sh, L, wt0.x) : MsClauseHdr{0, 0};
+        const MsClauseRec cr0 = live0 ? wl[wt0.x] : MsClauseRec{0, 0, 0, 0};
+        const int2 ww0 = make_int2(cr0.w0, cr0.w1);
+        const MsClauseHdr ch0 = MsClauseHdr{cr0.start, cr0.size};
 #else
         const int2 ww0 = make_int2(0, 0);
         const MsClauseHdr ch0 = MsClauseHdr{0, 0};
@@ -597,8 +596,9 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 const bool live = act && wt.x >= 0;
                 const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
 #if MS_SPECULATE
-                const int2 ww = live ? wl[wt.x] : make_int2(0, 0);
-                const MsClauseHdr ch = live ? clause_hdr_of(w, sh, L, wt.x) : MsClauseHdr{0, 0};
+                const MsClauseRec cr = live ? wl[wt.x] : MsClauseRec{0, 0, 0, 0};
+                const int2 ww = make_int2(cr.w0, cr.w1);
+                const MsClauseHdr ch = MsClauseHdr{cr.start, cr.size};
 #else
                 const int2 ww = make_int2(0, 0);
                 const MsClauseHdr ch = MsClauseHdr{0, 0};
@@ -1051,13 +1051,13 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
 DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
     MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
     int2* pool = WKA(int2, pool);
-    const int2* wl = WKA(int2, wl);
+    const MsClauseRec* wl = WKA(MsClauseRec, wl);
     const uint32_t nlist = 2 * sh.n_vars;
     const uint32_t ncl = sh.n_orig + w.n_learnts;
     for (uint32_t t = (uint32_t)w.lane; t < nlist; t += MS_WAVE) whdr[t].size = 0;
     wave_fence();
     for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
-        int2 ww = wl[c];
+        const int2 ww = make_int2(wl[c].w0, wl[c].w1);
         atomicAdd(&whdr[ww.x ^ 1].size, 1u);
         atomicAdd(&whdr[ww.y ^ 1].size, 1u);
     }
@@ -1080,7 +1080,7 @@ DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
     w.pool_top = run;
     wave_fence();
     for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
-        int2 ww = wl[c];
+        const int2 ww = make_int2(wl[c].w0, wl[c].w1);
         uint32_t pa = atomicAdd(&whdr[ww.x ^ 1].size, 1u);
         pool[whdr[ww.x ^ 1].base + pa] = make_int2((int)c, ww.y);
         uint32_t pb = atomicAdd(&whdr[ww.y ^ 1].size, 1u);
@@ -1096,7 +1096,7 @@ DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
 template <bool LV>
 DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
     volatile uint32_t* hist = w.hist;
-    MsClauseHdr* lc_hdr = WK_PTR(MsClauseHdr, w, L, lc_hdr);
+    MsClauseRec* lrec = WKA(MsClauseRec, wl) + sh.n_orig;   // records of the learnt clauses
     uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
     int32_t* lc_lits = WK_PTR(int32_t, w, L, lc_lits);
     uint32_t* remap = WK_PTR(uint32_t, w, L, remap);
@@ -1131,10 +1131,10 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
             uint32_t raw = lc_lbd[k];
             lb = raw & 0x7fffffffu;
             bool used = raw >> 31;
-            const MsClauseHdr ch = lc_hdr[k];
+            const MsClauseRec ch = lrec[k];
             o0 = ch.start;
             o1 = ch.start + ch.size;
-            ww = WKA(int2, wl)[sh.n_orig + k];
+            ww = make_int2(ch.w0, ch.w1);
             int cref = (int)(sh.n_orig + k);
             bool locked = (lit_value<LV>(w, sh, L, ww.x) == MS_VAL_TRUE && VREC[ww.x >> 1].reason == cref) ||
                           (lit_value<LV>(w, sh, L, ww.y) == MS_VAL_TRUE && VREC[ww.y >> 1].reason == cref);
@@ -1179,9 +1179,8 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
                 }
         }
         if (keep) {
-            lc_hdr[nkk] = MsClauseHdr{nlits + pre, len};
+            lrec[nkk] = MsClauseRec{ww.x, ww.y, nlits + pre, len};
             lc_lbd[nkk] = lb;  // clears the used bit
-            WKA(int2, wl)[sh.n_orig + nkk] = ww;
         }
         nk += nkeep;
         nlits += total;
@@ -1219,9 +1218,8 @@ DEV int add_learnt(Wk& w, const MsShared& sh, const MsLayout& L, int n, uint32_t
     const int l0 = uni(learnt_buf[0]), l1 = uni(learnt_buf[1]);
     const int cref = (int)(sh.n_orig + k);
     if (w.lane == 0) {
-        WK_PTR(MsClauseHdr, w, L, lc_hdr)[k] = MsClauseHdr{o, (uint32_t)n};
+        WKA(MsClauseRec, wl)[cref] = MsClauseRec{l0, l1, o, (uint32_t)n};
         WK_PTR(uint32_t, w, L, lc_lbd)[k] = lbd;
-        WKA(int2, wl)[cref] = make_int2(l0, l1);
     }
     w.n_learnts++;
     w.lc_lits_n += ((uint32_t)n + 3u) & ~3u;   // next clause starts 16-byte aligned

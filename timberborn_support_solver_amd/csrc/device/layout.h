@@ -82,12 +82,14 @@ struct MsVarRec { int32_t level, reason; uint8_t phase, seen; uint16_t mstamp; i
 struct MsVarHead { int32_t level, reason; uint32_t phase_seen_mstamp; };
 // Long / learnt clause header: literals start 16-byte aligned (4 literals) so that a lane reads 4 at a time.
 struct MsClauseHdr { uint32_t start, size; };
+// Per worker and clause (original long clauses first, then learnt ones): the two watched literals AND where the
+// literals are - ONE 16-byte access when a watcher's blocker is not true (was: a private pair + a header elsewhere).
+struct MsClauseRec { int32_t w0, w1; uint32_t start, size; };
 
 // Immutable, one per GPU.
 struct MsShared {
     uint32_t n_vars;
     uint32_t n_orig;               // long (>= 4 literal) original clauses, cref 0..n_orig-1
-    const MsClauseHdr* cl_hdr;     // n_orig headers into cl_lits
     const int32_t* cl_lits;        // literals of the long original clauses (each clause 16-byte aligned)
     const int32_t* bin_lits;       // implied literals q  (clause  ~p | q) of p being TRUE
     const ms_int2* tern_pairs;     // the other two literals (b, c) of clause (~p | b | c)
@@ -104,11 +106,10 @@ struct MsLayout {
     uint64_t trail;       // int32  [n_vars]
     uint64_t trail_lim;   // int32  [n_vars+1]
     uint64_t vm_order;    // int32  [vm_cap]   move-to-front queue as an append-only array
-    uint64_t wl;          // int2   [n_orig + learnt_cap]  the two watched literals per clause
+    uint64_t wl;          // MsClauseRec [n_orig + learnt_cap]  watched pair + literal range per clause
     uint64_t whdr;        // MsWatchHdr [2*n_vars]  the literal's watch list (slot in pool, size, capacity) + where its
                           //        binary / ternary lists are in the shared CSRs
     uint64_t pool;        // int2   [pool_cap]  watcher = (cref, blocker); cref < 0 = tombstone
-    uint64_t lc_hdr;      // MsClauseHdr [learnt_cap]
     uint64_t lc_lbd;      // uint32 [learnt_cap]  lbd | used<<31
     uint64_t lc_lits;     // int32  [learnt_lit_cap]  (each clause 16-byte aligned)
     uint64_t learnt_buf;  // int32  [n_vars+1]   clause under construction

@@ -275,7 +275,6 @@ struct mi355sat {
     // device
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf<MsClauseHdr> d_cl_hdr;
     DevBuf<int32_t> d_cl_lits, d_bin_lits, d_tern_owner;
     DevBuf<ms_int2> d_tern_pairs;
     bool lds_val = false;                      // assignment staged in LDS (2 bits/var)
@@ -563,9 +562,8 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     place(L.trail, 4 * (size_t)nv);
     place(L.trail_lim, 4 * ((size_t)nv + 1));
     place(L.vm_order, 4 * (size_t)L.vm_cap);
-    place(L.wl, 8 * ((size_t)no + L.learnt_cap));
+    place(L.wl, sizeof(MsClauseRec) * ((size_t)no + L.learnt_cap));
     place(L.whdr, sizeof(MsWatchHdr) * 2 * (size_t)nv);
-    place(L.lc_hdr, sizeof(MsClauseHdr) * (size_t)L.learnt_cap);
     place(L.lc_lbd, 4 * (size_t)L.learnt_cap);
     place(L.learnt_buf, 4 * ((size_t)nv + 1));
     place(L.toclear, 4 * ((size_t)nv + 1));
@@ -608,14 +606,14 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
         trail[i] = l;
         val[(l >> 1) >> 4] |= (2u | (uint32_t)(l & 1)) << (((l >> 1) & 15) * 2);
     }
-    int2* wl = (int2*)(T + L.wl);
+    MsClauseRec* wl = (MsClauseRec*)(T + L.wl);
     MsWatchHdr* whdr = (MsWatchHdr*)(T + L.whdr);
     int2* pool = (int2*)(T + L.pool);
     for (size_t t = 0; t < cap.size(); t++)
         whdr[t] = MsWatchHdr{base[t], 0, cap[t], 0, P.lit_hdr[t].bin_off, P.lit_hdr[t].bin_n, P.lit_hdr[t].tern_off, P.lit_hdr[t].tern_n};
     for (uint32_t c = 0; c < no; c++) {
         int32_t a = P.cl_lits[P.cl_hdr[c].start], b = P.cl_lits[P.cl_hdr[c].start + 1];
-        wl[c] = make_int2(a, b);
+        wl[c] = MsClauseRec{a, b, P.cl_hdr[c].start, P.cl_hdr[c].size};
         pool[whdr[a ^ 1].base + whdr[a ^ 1].size++] = make_int2((int)c, b);
         pool[whdr[b ^ 1].base + whdr[b ^ 1].size++] = make_int2((int)c, a);
     }
@@ -630,14 +628,12 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     build_layout_and_template(s, P, assump_cap, script_cap, tmpl);
     s.n_vars = P.n_vars;
     s.perm = P.perm;
-    s.d_cl_hdr.upload(P.cl_hdr.empty() ? std::vector<MsClauseHdr>{MsClauseHdr{0, 0}} : P.cl_hdr, s.stream);
     s.d_cl_lits.upload(P.cl_lits, s.stream);
     s.d_bin_lits.upload(P.bin_lits.empty() ? std::vector<int32_t>{0} : P.bin_lits, s.stream);
     s.d_tern_pairs.upload(P.tern_pairs.empty() ? std::vector<ms_int2>{ms_int2{0, 0}} : P.tern_pairs, s.stream);
     s.d_tern_owner.upload(P.tern_owner.empty() ? std::vector<int32_t>{0} : P.tern_owner, s.stream);
     s.sh.n_vars = P.n_vars;
     s.sh.n_orig = (uint32_t)P.cl_hdr.size();
-    s.sh.cl_hdr = s.d_cl_hdr.p;
     s.sh.cl_lits = s.d_cl_lits.p;
     s.sh.bin_lits = s.d_bin_lits.p;
     s.sh.tern_pairs = s.d_tern_pairs.p;
@@ -1253,7 +1249,7 @@ void mi355sat_free(mi355sat* s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     delete s->sweep;
-    s->d_cl_hdr.release(); s->d_cl_lits.release(); s->d_bin_lits.release();
+    s->d_cl_lits.release(); s->d_bin_lits.release();
     s->d_tern_pairs.release(); s->d_tern_owner.release();
     s->d_template.release(); s->d_slabs.release(); s->d_states.release(); s->d_any_done.release();
     s->d_proof.release(); s->d_proof_len.release();
