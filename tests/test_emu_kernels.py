@@ -266,3 +266,44 @@ def test_emulated_solver_loop_sweep_prints_the_reference_messages():
     assert "Solution found (3 platforms total)" in lines and lines[-1] == "No solution found for the current constraints"
     with pytest.raises(ValueError):
         solver_loop_sweep(grid, enc, PlatformLimits({(1, 1): 3}, weights={(1, 1): 2}, weight_limit=5))
+
+
+def test_emulated_assignment_in_hbm_variant(tmp_path):
+    """lds_val=-1 forces the variant the large instances run (the small test instances would otherwise stage the
+    2-bit assignment in LDS): the assignment stays in HBM behind relaxed agent-scope atomics.  Verdicts, models,
+    a checked DRUP proof and bit-exact BCP fixpoints through that path."""
+    for terrain, plats, k in [("ex1", "1x1", 3), ("rect8x8", "1x1", 3), ("rect8x8", "default", 2)]:
+        v = [x for x in VERDICTS["verdicts"] if (x["terrain"], x["platforms"], x["k"]) == (terrain, plats, k)][0]
+        grid = make_grid(terrain)
+        enc = Encoding.encode(platform_defs(plats), grid)
+        cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+        s = emu_solver(workers=4, slice_conflicts=50, lds_val=-1)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        r = s.solve()
+        assert r.name.upper() == v["verdict"]
+        if r == SolverResult.Sat:
+            check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+        s.close()
+    grid = make_grid("ex1")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 2}))
+    proof = str(tmp_path / "p.drup")
+    s = emu_solver(workers=1, slice_conflicts=50, lds_val=-1)
+    s.set_proof_path(proof)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    assert s.solve() == SolverResult.Unsat
+    s.close()
+    assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof)) == 1
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("default"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 6}))
+    scripts = [scripted_decisions(enc, grid, seed, 6) for seed in range(1, 6)] + [[]]
+    s = emu_solver(lds_val=-1)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    confl, vals, tl = s.propagate_batch(scripts, n_vars=cnf.n_vars)
+    for i, dec in enumerate(scripts):
+        c, v, n, _ = ora.bcp(cnf.lits, cnf.offsets, cnf.n_vars, dec)
+        assert c == confl[i]
+        if not c:
+            assert np.array_equal(v, vals[i]) and n == tl[i]
+    s.close()
