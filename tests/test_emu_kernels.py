@@ -272,6 +272,7 @@ def test_emulated_assignment_in_hbm_variant(tmp_path):
     """lds_val=-1 forces the variant the large instances run (the small test instances would otherwise stage the
     2-bit assignment in LDS): the assignment stays in HBM behind relaxed agent-scope atomics.  Verdicts, models,
     a checked DRUP proof and bit-exact BCP fixpoints through that path."""
+    from timberborn_support_solver_amd.dimacs import read_drup
     for terrain, plats, k in [("ex1", "1x1", 3), ("rect8x8", "1x1", 3), ("rect8x8", "default", 2)]:
         v = [x for x in VERDICTS["verdicts"] if (x["terrain"], x["platforms"], x["k"]) == (terrain, plats, k)][0]
         grid = make_grid(terrain)
