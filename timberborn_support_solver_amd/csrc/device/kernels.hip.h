@@ -703,12 +703,16 @@ template <bool LV>
 DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
     const int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
     const MsVarRec* vrec = VREC;
+    // Every candidate costs two random lines (its record for the liveness check, its assignment word).  The next
+    // unassigned variable is usually among the first few entries (the search position follows the queue front),
+    // so the first probe looks at 16 candidates only and only a miss widens to the whole wave.
+    int width = 16;
     for (;;) {
         if (w.vm_search < 0) return -1;
         int idx = w.vm_search - w.lane;
         int v = -1;
         bool ok = false;
-        if (idx >= 0) {
+        if (w.lane < width && idx >= 0) {
             v = vm_order[idx];
             ok = vrec[v].vm_pos == idx && lit_value<LV>(w, sh, L, 2 * v) == MS_VAL_UNDEF;
         }
@@ -718,7 +722,8 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
             w.vm_search -= f;
             return bcast(v, f);
         }
-        w.vm_search -= MS_WAVE;
+        w.vm_search -= width;
+        width = MS_WAVE;
     }
 }
 
