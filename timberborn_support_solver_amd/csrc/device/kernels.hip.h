@@ -853,11 +853,13 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
             analyze_visit(w, sh, L, vrec, toclear, learnt_buf, w.lane < kind && q != p, q, dl, path_c, n_out, n_clear);
         }
         wave_fence();
-        // walk the trail back to the most recent literal marked seen
-        for (;;) {
+        // walk the trail back to the most recent literal marked seen: 16 entries first (each costs a random
+        // variable-record line and the next one is usually close), the whole wave only when those miss
+        for (int width = 16;; width = MS_WAVE) {
             int i = index - w.lane;
-            int l = i >= 0 ? WKA(int32_t, trail)[i] : 0;
-            bool ok = i >= 0 && vrec[l >> 1].seen;
+            const bool in = w.lane < width && i >= 0;
+            int l = in ? WKA(int32_t, trail)[i] : 0;
+            bool ok = in && vrec[l >> 1].seen;
             u64 m = ballot(ok);
             if (m) {
                 int f = first_lane(m);
@@ -865,7 +867,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
                 p = bcast(l, f);
                 break;
             }
-            index -= MS_WAVE;
+            index -= width;
             if (index < 0) { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
         }
         index--;
