@@ -13,7 +13,7 @@ grid = WorldGrid.rect(size, size)
 enc = Encoding.encode(PLATFORMS_DEFAULT, grid)
 cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
 for kw in (dict(),):
-    s = Mi355Sat(workers=W, slice_ms=slc, conflict_budget=1, verbose=1, _lib_override=prof, **kw)
+    s = Mi355Sat(workers=W, slice_ms=slc, conflict_budget=1, verbose=1, ramp=-1, share=-1, _lib_override=prof, **kw)
     s.add_cnf(cnf.lits, cnf.offsets)
     t = time.time(); r = s.solve(); dt = time.time() - t
     st = s.stats()
