@@ -57,3 +57,4 @@ def test_signature_and_opts_struct_layout():
     assert st_size.value == ctypes.sizeof(Mi355SatStats) == 8 * (9 + 4 + 8 + 8)           # as the compiler laid them out
     L.mi355sat_signature.restype = ctypes.c_char_p
     assert b"mi355sat" in L.mi355sat_signature()
+    L.mi355sat_release_cached_memory()        # nothing parked, no device touched: must be a no-op
