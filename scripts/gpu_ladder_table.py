@@ -1,0 +1,36 @@
+"""Wall-clock of the refinement loop `-l1:M` on rect M x M: the product's batch loop on the GPU (3 runs) against
+the CPU restatement's sequential loop on the GPU box's host (1 core).  GPU box only."""
+import sys
+import time
+
+sys.path.insert(0, ".")
+from oracle import oracle as ora  # noqa: E402  (diagnostic script: the CPU side is the checker's solver)
+from timberborn_support_solver_amd import (Encoding, Mi355Sat, PlatformLayout, PlatformLimits, SolverResult, WorldGrid,  # noqa: E402
+                                           solver_loop_sweep)
+from timberborn_support_solver_amd.encoder import PLATFORMS_DEFAULT  # noqa: E402
+
+sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [16, 20, 24, 26]
+for m in sizes:
+    g = WorldGrid.rect(m, m)
+    e = Encoding.encode(PLATFORMS_DEFAULT, g)
+    k, tc, kstar, confl = m, time.perf_counter(), None, 0
+    while time.perf_counter() - tc < 240:
+        ck = e.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+        o = ora.OracleSolver()
+        o.add_cnf(ck.lits, ck.offsets)
+        r = o.solve(conflict_budget=20_000_000)
+        confl += o.stats()["conflicts"]
+        if r == 20:
+            kstar = k + 1
+            break
+        if r != 10:
+            break
+        k = PlatformLayout.from_assignment(o.model(ck.n_vars)[:e.n_vars], e).platform_count() - 1
+    cpu_s = time.perf_counter() - tc
+    gpu = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=150, make_solver=lambda: Mi355Sat(slice_ms=10))
+        ok = hist[-1]["result"] == SolverResult.Unsat
+        gpu.append((round(time.perf_counter() - t0, 2), [h["count"] for h in hist if h["count"]][-1] if ok else None))
+    print(f"rect {m} -l1:{m}: CPU {cpu_s:.2f} s (k*={kstar}, {confl} conflicts) | GPU batch loop {gpu}", flush=True)
