@@ -27,10 +27,12 @@ for m in sizes:
             break
         k = PlatformLayout.from_assignment(o.model(ck.n_vars)[:e.n_vars], e).platform_count() - 1
     cpu_s = time.perf_counter() - tc
+    print(f"rect {m}: CPU done in {cpu_s:.1f} s", flush=True)   # (keeps a long rung from looking hung)
     gpu = []
     for rep in range(3):
         t0 = time.perf_counter()
         hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=150, make_solver=lambda: Mi355Sat(slice_ms=10))
         ok = hist[-1]["result"] == SolverResult.Unsat
         gpu.append((round(time.perf_counter() - t0, 2), [h["count"] for h in hist if h["count"]][-1] if ok else None))
+        print(f"rect {m}: GPU run {rep} {gpu[-1]}", flush=True)
     print(f"rect {m} -l1:{m}: CPU {cpu_s:.2f} s (k*={kstar}, {confl} conflicts) | GPU batch loop {gpu}", flush=True)
