@@ -192,11 +192,20 @@ int mi355sat_model_of(mi355sat* s, uint64_t instance, int8_t* out, uint64_t n_va
 
 /* --- Interrupt::interrupter / InterruptSolver::interrupt ------------------ */
 /* Async, thread-safe, idempotent: only sets a flag that solve() polls between
- * kernel launches (and the kernels poll from pinned host memory). */
+ * kernel launches (and the kernels poll from pinned host memory).  The solve it stops returns
+ * MI355SAT_INTERRUPTED and consumes the flag; an interrupt that arrives while no solve is running
+ * stops the next solve / batch / sweep at once (it is not lost) and is consumed by that one. */
 void mi355sat_interrupt(mi355sat* s);
 
 /* --- SolveStats::stats ----------------------------------------------------- */
 int mi355sat_stats(const mi355sat* s, mi355sat_stats_t* out);
+
+/* Test hook: the learnt clauses currently in the exchange ring of the last solve / batch / sweep, as DIMACS
+ * literals, each clause 0-terminated.  out may be NULL to size the buffer; *n_records receives the number of
+ * clauses.  Every one of them must be a consequence of the caller's formula alone (workers attach them under
+ * any assumption set) - tests/ prove that with the oracle.  Returns 0, or MI355SAT_ERR_ARG if cap_words is
+ * too small. */
+int mi355sat_debug_share_ring(mi355sat* s, int32_t* out, uint64_t cap_words, uint64_t* n_records);
 
 /* Optional DRUP proof (text, DIMACS literals, one learnt clause per line in derivation order, the
  * empty clause last) of the next plain solve().  Logging makes that solve use ONE worker (a proof is

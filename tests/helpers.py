@@ -77,12 +77,53 @@ def scripted_decisions(enc, grid, seed, n_decisions, p_positive=0.35):
     return dec
 
 
+_oracle_enc = {}
+
+
+def oracle_encoding(enc, grid):
+    """The oracle's literal restatement of the encoder for the same terrain / platform set (cached: it is
+    pure Python).  Its variable numbering equals the product's (tests/test_encoder.py proves the CNFs
+    bit-exact), so product models can be read through it."""
+    from oracle import encoder_oracle as eo
+    key = (tuple(grid.rows()), tuple(enc.defs))
+    if key not in _oracle_enc:
+        _oracle_enc[key] = eo.Encoding(list(enc.defs), eo.grid_from_rows(grid.rows()))
+    return _oracle_enc[key]
+
+
 def check_sat_answer(cnf, model, enc, grid, k):
-    """A SAT answer is right iff the model satisfies every clause, the layout validates and has <= k platforms."""
-    from oracle import oracle as ora
+    """A SAT answer is right iff the model satisfies every clause, the layout validates and has <= k
+    platforms.  Layout and validity are derived twice: by the product (libtbs_host.so) and by the
+    oracle's restatement of platform_layout.rs (oracle/layout_oracle.py) - on the GPU box the product's
+    validator must not be its own judge."""
+    from oracle import layout_oracle as lo, oracle as ora
     from timberborn_support_solver_amd import PlatformLayout
     assert ora.check_model(cnf.lits, cnf.offsets, model) == -1
     lay = PlatformLayout.from_assignment(model[:enc.n_vars], enc)
     assert lay.validate(grid).is_valid()
     assert lay.platform_count() <= k
+    o = oracle_encoding(enc, grid)
+    q = lo.from_assignment(np.asarray(model[:enc.n_vars]).tolist(), o)
+    assert lo.is_valid(lo.validate(q, o.grid)) and lo.platform_count(q) <= k
+    assert sorted(lay.platforms()) == sorted((x, y, d[0], d[1], int(r)) for (x, y), (d, r) in q.items())
     return lay
+
+
+def assert_ring_records_are_implied(solver, cnf, max_records=None):
+    """Exchange soundness: every clause in the learnt-clause exchange ring must follow from the caller's
+    formula ALONE (workers attach ring records under any assumption set and declare UNSAT when one is
+    falsified at level 0).  The oracle solver refutes formula AND NOT(clause) for each record."""
+    from oracle import oracle as ora
+    recs = solver.debug_share_ring()
+    o = ora.OracleSolver()
+    o.add_cnf(cnf.lits, cnf.offsets)
+    o.reserve(cnf.n_vars)
+    seen = set()
+    for c in recs[:max_records]:
+        assert 1 <= len(c) <= 31 and all(l != 0 and abs(l) <= cnf.n_vars for l in c), c
+        key = tuple(sorted(c))
+        if key in seen:
+            continue
+        seen.add(key)
+        assert o.solve([-l for l in c]) == 20, ("exchange ring holds a clause the formula does not imply", c)
+    return len(recs)

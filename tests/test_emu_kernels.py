@@ -8,7 +8,7 @@ import time
 import numpy as np
 import pytest
 
-from helpers import VERDICTS, check_sat_answer, emu_lib, make_grid, platform_defs, scripted_decisions
+from helpers import assert_ring_records_are_implied, VERDICTS, check_sat_answer, emu_lib, make_grid, platform_defs, scripted_decisions
 from oracle import oracle as ora
 from timberborn_support_solver_amd import Encoding, Mi355Sat, PlatformLimits, SolverResult, solver_loop
 
@@ -113,7 +113,17 @@ def test_interrupt_from_another_thread_and_conflict_budget():
     t0 = time.time()
     assert s.solve() == SolverResult.Interrupted
     assert time.time() - t0 < 60 and s.stats()["n_terminated"] == 1
+    # the interrupt was consumed by the solve it stopped: the same handle searches again ...
+    threading.Timer(1.0, intr.interrupt).start()
+    t0 = time.time()
+    assert s.solve() == SolverResult.Interrupted and time.time() - t0 > 0.5
+    # ... and one that arrives while nothing runs is not lost: it stops the next solve at once, only that one
+    intr.interrupt()
+    t0 = time.time()
+    assert s.solve() == SolverResult.Interrupted and time.time() - t0 < 0.5
+    assert s.stats()["n_terminated"] == 3
     s.close()
+    intr.interrupt()   # after close(): a no-op, not a call into a freed handle
     s = emu_solver(workers=1, slice_conflicts=5, conflict_budget=10)
     s.add_cnf(cnf.lits, cnf.offsets)
     assert s.solve() == SolverResult.Interrupted
@@ -208,6 +218,22 @@ def test_emulated_clause_exchange_and_locality_order():
     s.add_cnf(cnf.lits, cnf.offsets)
     assert s.solve() == SolverResult.Sat
     check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, 4)
+    s.close()
+
+
+def test_emulated_exchange_ring_holds_only_consequences_of_the_formula():
+    """A sweep over several bounds with the exchange on: what workers of one instance put into the ring is
+    attached by workers of every other instance, so each record must follow from the formula alone - in
+    particular it must not depend on any instance's assumption (the at-most-k bound)."""
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 8}), sweep=True)
+    ks = [8, 5, 4, 3, 2]
+    s = emu_solver(workers=10, slice_conflicts=16, share_lbd=6)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    res = s.solve_batch([[-int(cnf.card_outputs[k])] if k < 8 else [] for k in ks])
+    assert [r.name for r in res] == ["Sat", "Sat", "Sat", "Unsat", "Unsat"]
+    assert assert_ring_records_are_implied(s, cnf) > 0
     s.close()
 
 

@@ -668,6 +668,8 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.share_slots = 0;
     if (s.opts.share >= 0 && W > 1 && s.proof_path.empty() && script_cap == 0) {
         s.share_slots = 1u << 19;   // 64 MiB of records
+        while ((uint64_t)s.share_slots < (uint64_t)W * MS_EXPORT_RECS) s.share_slots <<= 1;   // one collection (<= W * MS_EXPORT_RECS
+                                                                                              // records) never wraps onto itself
         s.share_hash_n = 1u << 22;
         s.d_share_pool.alloc((size_t)s.share_slots * MS_SHARE_REC);
         s.d_share_n.alloc(1);
@@ -1164,9 +1166,16 @@ bool sweep_finished(const mi355sat& s, const Sweep& sw) {
     return false;
 }
 
+// An interrupt is consumed by the solve it stops (or, if it came before solve(), by the next one, which
+// returns INTERRUPTED at once): later solves on the same handle run normally.
+void consume_interrupt(mi355sat& s) {
+    if (s.interrupted.exchange(0)) __atomic_store_n(s.stop_flag, 0, __ATOMIC_SEQ_CST);
+}
+
 void sweep_end(mi355sat& s, Sweep& sw) {
     if (sw.active) accumulate_stats(s, sw.sts);
     sw.active = false;
+    consume_interrupt(s);
 }
 
 int run_search(mi355sat& s, const std::vector<int32_t>& assump, const std::vector<uint64_t>& assump_off,
@@ -1545,6 +1554,7 @@ int mi355sat_sweep_end(mi355sat* s) {
         for (uint32_t i = 0; i < sw.n_instances; i++)
             if (sw.results[i] == MI355SAT_SAT && sw.winner[i] >= 0)
                 fetch_model(*s, (uint32_t)sw.winner[i], s->batch_models[i], s->max_var);
+        consume_interrupt(*s);
         delete s->sweep;
         s->sweep = nullptr;
         return 0;
@@ -1577,6 +1587,40 @@ int mi355sat_model_of(mi355sat* s, uint64_t instance, int8_t* out, uint64_t n_va
     const auto& m = s->batch_models[instance];
     for (uint64_t v = 0; v < n_vars; v++) out[v] = v < m.size() ? m[v] : 0;
     return 0;
+}
+
+int mi355sat_debug_share_ring(mi355sat* s, int32_t* out, uint64_t cap_words, uint64_t* n_records) {
+    if (!s || !n_records) return MI355SAT_ERR_ARG;
+    *n_records = 0;
+    if (!s->share_slots || !s->d_share_pool.p) return 0;
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        unsigned long long n = 0;
+        HIPCHK(hipMemcpy(&n, s->d_share_n.p, sizeof n, hipMemcpyDeviceToHost));
+        const uint64_t live = std::min<uint64_t>(n, s->share_slots);
+        std::vector<int32_t> ring((size_t)live * MS_SHARE_REC);
+        if (live) HIPCHK(hipMemcpy(ring.data(), s->d_share_pool.p, ring.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> inv(s->perm.size());
+        for (uint32_t e = 0; e < s->perm.size(); e++) inv[s->perm[e]] = e;
+        uint64_t w = 0;
+        for (uint64_t r = 0; r < live; r++) {
+            const int32_t* rec = ring.data() + r * MS_SHARE_REC;
+            const int sz = rec[0] & 63;
+            if (sz < 1 || sz > MS_SHARE_MAXLEN) { s->err = "malformed record in the exchange ring"; return MI355SAT_ERR_STATE; }
+            if (out && w + (uint64_t)sz + 1 <= cap_words) {
+                for (int j = 1; j <= sz; j++) {
+                    if (rec[j] < 0 || (uint32_t)(rec[j] >> 1) >= inv.size()) { s->err = "literal out of range in the exchange ring"; return MI355SAT_ERR_STATE; }
+                    out[w + j - 1] = (rec[j] & 1) ? -((int32_t)inv[rec[j] >> 1] + 1) : ((int32_t)inv[rec[j] >> 1] + 1);
+                }
+                out[w + sz] = 0;
+            }
+            w += (uint64_t)sz + 1;
+            (*n_records)++;
+        }
+        return w <= cap_words || !out ? 0 : MI355SAT_ERR_ARG;
+    } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
+    catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
 }
 
 int mi355sat_stats(const mi355sat* s, mi355sat_stats_t* out) {

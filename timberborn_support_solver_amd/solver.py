@@ -17,6 +17,7 @@ analogue of the reference's `anyhow::Result`.
 """
 import ctypes
 import enum
+import threading
 
 import numpy as np
 
@@ -93,6 +94,7 @@ def _bind(L):
     L.mi355sat_interrupt.argtypes = [vp]
     L.mi355sat_stats.argtypes = [vp, ctypes.POINTER(Mi355SatStats)]
     L.mi355sat_set_proof_path.argtypes = [vp, ctypes.c_char_p]
+    L.mi355sat_debug_share_ring.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     return L
 
 
@@ -106,13 +108,14 @@ def _p(a):
 class Interrupter:
     """`S::Interrupter`: Send + 'static, callable from another thread while solve() runs."""
 
-    def __init__(self, lib, handle_ref):
-        self._lib, self._ref = lib, handle_ref
+    def __init__(self, lib, handle_ref, lock):
+        self._lib, self._ref, self._lock = lib, handle_ref, lock
 
     def interrupt(self):
-        h = self._ref[0]
-        if h:
-            self._lib.mi355sat_interrupt(h)
+        with self._lock:   # close() clears the reference under the same lock before it frees the handle
+            h = self._ref[0]
+            if h:
+                self._lib.mi355sat_interrupt(h)
 
 
 class Mi355Sat:
@@ -131,13 +134,15 @@ class Mi355Sat:
         if not self._h:
             raise SolverError("mi355sat_new failed: " + (self._L.mi355sat_last_error(None) or b"").decode())
         self._ref = [self._h]
+        self._lock = threading.Lock()
         self._n_vars = 0
 
     def close(self):
         if getattr(self, "_h", None):
+            with self._lock:   # no interrupter may still be inside mi355sat_interrupt(), none may enter afterwards
+                self._ref[0] = None
             self._L.mi355sat_free(self._h)
             self._h = None
-            self._ref[0] = None
 
     __del__ = close
 
@@ -169,7 +174,7 @@ class Mi355Sat:
         self._n_vars = max(self._n_vars, n_vars)
 
     def interrupter(self):
-        return Interrupter(self._L, self._ref)
+        return Interrupter(self._L, self._ref, self._lock)
 
     def solve(self):
         return SolverResult(self._check(self._L.mi355sat_solve(self._h), "solve"))
@@ -228,6 +233,29 @@ class Mi355Sat:
         self._check(self._L.mi355sat_propagate_batch(self._h, _p(flat), _p(offs), n, _p(vals) if want_values else None,
                                                      n_vars, _p(confl), _p(tl), repeat), "propagate_batch")
         return confl, vals, tl
+
+    def debug_share_ring(self):
+        """Test hook: the clauses in the learnt-clause exchange ring, as lists of DIMACS literals."""
+        n = ctypes.c_uint64(0)
+        cap = 1 << 16
+        while True:
+            buf = np.zeros(cap, dtype=np.int32)
+            rc = self._L.mi355sat_debug_share_ring(self._h, _p(buf), cap, ctypes.byref(n))
+            if rc == -4:
+                cap *= 4
+                continue
+            self._check(rc, "debug_share_ring")
+            break
+        out, cur = [], []
+        for l in buf.tolist():
+            if len(out) == n.value:
+                break
+            if l == 0:
+                out.append(cur)
+                cur = []
+            else:
+                cur.append(l)
+        return out
 
     def set_proof_path(self, path):
         """DRUP proof of the next solve() (forces a single worker)."""
