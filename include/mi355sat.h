@@ -87,6 +87,9 @@ typedef struct mi355sat_opts {
     int32_t ramp;              /* 0 = default (on): the first 100 ms of kernel time of a solve run 256 workers (one per
                                   CU, each ~3x faster than one of 16), the next 300 ms 1024, then all - easy instances
                                   are decided by one worker's few hundred conflicts; -1 = the whole fleet at once */
+    int32_t one_per_simd;      /* 0 = default: a launch of at most 1024 workers (one per SIMD) runs the build of the search
+                                  kernel that owns the SIMD's whole register file (no spills, everything inlined);
+                                  -1 = always the 4-waves-per-SIMD build (A/B) */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
 } mi355sat_opts;
@@ -164,6 +167,10 @@ int mi355sat_sweep_step(mi355sat* s, int32_t* results /* may be NULL */, uint64_
  * SAT one and every k below an UNSAT one is implied).  Their result stays 0, they count as decided, and
  * their workers move to the instances still open - as do the workers of every instance that gets its verdict. */
 int mi355sat_sweep_drop(mi355sat* s, const uint64_t* instances, uint64_t n);
+/* Take withdrawn, still undecided instances up again: idle workers (parked, or of decided / withdrawn instances)
+ * move to them.  The sharded sweep (one process per GPU) begins every rank with all bounds, withdraws
+ * the other ranks' shards, and reopens the bounds still open anywhere once its own shard is decided. */
+int mi355sat_sweep_reopen(mi355sat* s, const uint64_t* instances, uint64_t n);
 /* Model of an instance that already reported SAT, while the sweep is still running (the loop needs the
  * layout's platform count to know which bounds it answers). */
 int mi355sat_sweep_model_of(mi355sat* s, uint64_t instance, int8_t* out, uint64_t n_vars);

@@ -49,3 +49,61 @@ def test_two_rank_cut_exchange_gloo():
     assert ks0 == [20, 18, 16, 14, 12, 10] and ks1 == [19, 17, 15, 13, 11, 9]      # k_hi - rank - i*world
     assert s0 == s1 == 14 and u0 == u1 == 13 and d0 and d1                          # cut closed: 13 + 1 == 14
     assert m0 == m1 == [1.0] * 8                                                   # broadcast from the rank owning k=14
+
+
+def _sharded_worker(rank, world, port, q, terrain, pset, k0):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import check_sat_answer, emu_lib, make_grid, platform_defs
+    from timberborn_support_solver_amd import Encoding, Mi355Sat, PlatformLimits
+    from timberborn_support_solver_amd.sweep import solver_loop_sweep_sharded
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    lines, st = [], {}
+    # real solves: the product's kernels in the wavefront-emulator build, a few workers per rank
+    hist = solver_loop_sweep_sharded(grid, enc, PlatformLimits({(1, 1): k0}), out=lines.append, time_limit=600,
+                                     make_solver=lambda: Mi355Sat(_lib_override=emu_lib(), workers=6, slice_conflicts=30,
+                                                                  seed=100 + rank),
+                                     stats_out=st)
+    best = [h for h in hist if h["result"].name == "Sat"][-1]
+    model = best["model"]
+    model = model.tolist() if hasattr(model, "tolist") else list(model)
+    q.put((rank, [(h["k"], h["result"].name, h["count"], h["valid"]) for h in hist], [int(x) for x in model], lines,
+           st.get("stats", {}).get("conflicts", 0)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("terrain,pset,k0,kstar", [("rect8x8", "1x1", 8, 4), ("ex1", "1x1", 10, 3)])
+def test_two_rank_sharded_sweep_with_real_solves_gloo(terrain, pset, k0, kstar):
+    """SURVEY 8e end to end on CPU: two ranks over gloo, each driving the product's search kernels (emulator
+    build) on its shard of bounds k = k_hi - rank - i*world; the cut all-reduce + model broadcast make both
+    ranks return the same history, and the optimum is the golden one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, terrain, pset, k0)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, h0, m0, lines0, c0), (_, h1, m1, lines1, c1) = out
+    assert h0 == h1 and m0 == m1                                    # both ranks agree on cut and model
+    assert h0[-1] == (kstar - 1, "Unsat", None, None)
+    sat = [h for h in h0 if h[1] == "Sat"]
+    assert sat[-1][2] == kstar and all(h[3] for h in sat)
+    assert lines0[-1] == "No solution found for the current constraints" and lines1 == []   # rank 0 speaks
+    assert f"Solution found ({kstar} platforms total)" in lines0
+    assert c0 > 0 and c1 > 0                                        # both ranks really searched
+    # the agreed model is a model of the CNF at its own count (checked with the oracle)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from helpers import check_sat_answer, make_grid, platform_defs
+    from timberborn_support_solver_amd import Encoding, PlatformLayout, PlatformLimits
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    lay = PlatformLayout.from_assignment(np.asarray(m0, dtype=np.int8), enc)
+    assert lay.platform_count() == kstar and lay.validate(grid).is_valid()

@@ -1367,7 +1367,7 @@ DEV void import_shared(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& 
 // A conflict was found by propagate(): learn, backjump, assert (Glucose `search` conflict branch).
 // Returns true when a restart or a learnt-clause reduction is due at the next fixpoint.
 template <bool LV>
-DEV_COLD bool on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls) {
+DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls) {
     PROF_DECL
     ls.conflicts++;
     if (w.n_levels == 0) { w.status = MS_ST_UNSAT; return false; }
@@ -1426,10 +1426,12 @@ DEV_COLD bool on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     const bool import_due = ls.share_pool && ls.share_n > ls.share_pos && ls.conflicts - ls.last_import_confl >= ls.share_interval;
     return restart_due || reduce_due || import_due;
 }
+template <bool LV>
+DEV_COLD bool on_conflict(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls) { return on_conflict_body<LV>(w, sh, L, ls); }
 
 // BCP reached a fixpoint without conflict: restart? reduce? then assumptions / next decision.
 template <bool LV>
-DEV_COLD void on_fixpoint(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls, uint32_t reduce_first,
+DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls, uint32_t reduce_first,
                           uint32_t reduce_inc) {
     PROF_DECL
     if (ls.lbdq_n == MS_LBDQ && ((double)ls.lbdq_sum / MS_LBDQ) * 0.8 > (double)ls.lbd_total / (double)ls.conflicts) {
@@ -1472,6 +1474,10 @@ DEV_COLD void on_fixpoint(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);
     PROF_MARK(PF_DECIDE);
 }
+template <bool LV>
+DEV_COLD void on_fixpoint(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls, uint32_t reduce_first, uint32_t reduce_inc) {
+    on_fixpoint_body<LV>(w, sh, L, ls, reduce_first, reduce_inc);
+}
 
 // grid = n_workers blocks of 64 threads.  Runs each worker until it has a verdict,
 // or has spent its slice (conflicts / propagations), or the host / another worker
@@ -1479,8 +1485,11 @@ DEV_COLD void on_fixpoint(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
 // relaunches the kernel to continue.  LV = assignment staged in (dynamic) LDS.
 // The loop body is propagate() plus two cold calls working on a scratch copy of the
 // worker context, so the register allocation is that of the BCP loop.
-template <bool LV>
-__global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
+// ONE = the build for a fleet of at most one worker per SIMD (<= 1024 workers): the whole register file of the
+// SIMD is the worker's (no spills, no scratch copies: the per-conflict and per-fixpoint code is inlined), which is
+// what counts when nothing else hides a wave's latencies.
+template <bool LV, bool ONE>
+__global__ __launch_bounds__(MS_WAVE, ONE ? 1 : MS_SEARCH_WAVES_PER_SIMD) void ms_search_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
     __shared__ uint32_t s_hist[64];
@@ -1520,10 +1529,7 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     uint32_t slice_confl = 0;
     const bool entered_running = w.status == MS_ST_RUNNING;
     if (entered_running && st->restart_req) {   // a new cube was assigned: drop the old search path
-        Wk t = w;
-        cancel_until<LV>(t, sc, lc, 0);
-        w = t;
-        wk_uniformize(w);
+        cancel_until<LV>(w, sh, L, 0);
         if (w.lane == 0) st->restart_req = 0;
     }
     const u64 tick0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
@@ -1531,10 +1537,13 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
     while (w.status == MS_ST_RUNNING) {
         if (prm.slice_ticks && __builtin_amdgcn_s_memrealtime() - tick0 >= prm.slice_ticks) break;
         if (propagate<LV>(w, sh, L)) {
-            Wk t = w;
-            maintenance_due = on_conflict<LV>(t, sc, lc, ls);
-            w = t;
-            wk_uniformize(w);
+            if (ONE) maintenance_due = on_conflict_body<LV>(w, sh, L, ls);
+            else {
+                Wk t = w;
+                maintenance_due = on_conflict<LV>(t, sc, lc, ls);
+                w = t;
+                wk_uniformize(w);
+            }
             slice_confl++;
             if (slice_confl >= prm.slice_conflicts) break;
             if ((slice_confl & 63) == 0) {
@@ -1546,10 +1555,14 @@ __global__ __launch_bounds__(MS_WAVE, MS_SEARCH_WAVES_PER_SIMD) void ms_search_k
             if (w.status != MS_ST_RUNNING) break;
             if (prm.slice_props && w.c_props >= prm.slice_props) break;
             if (maintenance_due || w.n_levels < n_assumps_reg || w.pool_top > L.pool_cap - L.pool_cap / 4) {
-                Wk t = w;   // restart / reduce / watch GC / assumptions: the full (cold) path
-                on_fixpoint<LV>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc);
-                w = t;
-                wk_uniformize(w);
+                // restart / reduce / watch GC / assumptions: the full (cold) path
+                if (ONE) on_fixpoint_body<LV>(w, sh, L, ls, prm.reduce_first, prm.reduce_inc);
+                else {
+                    Wk t = w;
+                    on_fixpoint<LV>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc);
+                    w = t;
+                    wk_uniformize(w);
+                }
                 maintenance_due = false;
             } else {        // common case: just the next decision
                 PROF_DECL

@@ -829,8 +829,14 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     const uint32_t dyn = s.lds_val ? s.lds_val_bytes : 0;
     HIPCHK(hipEventRecord(s.ev0, s.stream));
     if (mode == 0) {
-        if (s.lds_val) hipLaunchKernelGGL(ms_search_kernel<true>, dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
-        else hipLaunchKernelGGL(ms_search_kernel<false>, dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        const bool one = s.opts.one_per_simd >= 0 && active <= 1024;   // at most one worker per SIMD: the no-spill build
+        if (s.lds_val) {
+            if (one) hipLaunchKernelGGL((ms_search_kernel<true, true>), dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+            else hipLaunchKernelGGL((ms_search_kernel<true, false>), dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        } else {
+            if (one) hipLaunchKernelGGL((ms_search_kernel<false, true>), dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+            else hipLaunchKernelGGL((ms_search_kernel<false, false>), dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        }
     } else {
         if (s.lds_val) hipLaunchKernelGGL(ms_bcp_kernel<true>, dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
         else hipLaunchKernelGGL(ms_bcp_kernel<false>, dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
@@ -1523,6 +1529,29 @@ int mi355sat_sweep_drop(mi355sat* s, const uint64_t* instances, uint64_t n) {
         if (any && sw.active && !sw.split && sw.decided < sw.n_instances) {
             if (sw.sts.size() != s->n_workers) gather_states(*s, sw.sts);
             rebalance_workers(*s, sw);
+        }
+        return 0;
+    } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
+    catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
+}
+
+int mi355sat_sweep_reopen(mi355sat* s, const uint64_t* instances, uint64_t n) {
+    if (!s || !s->sweep || (n && !instances)) return MI355SAT_ERR_STATE;
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        Sweep& sw = s->sweep->sw;
+        bool any = false;
+        for (uint64_t j = 0; j < n; j++) {
+            if (instances[j] >= sw.n_instances) { s->err = "instance out of range"; return MI355SAT_ERR_ARG; }
+            const uint64_t i = instances[j];
+            if (!sw.dropped[i] || sw.results[i] != MI355SAT_INTERRUPTED) continue;   // only what was withdrawn undecided
+            sw.dropped[i] = 0;
+            sw.decided--;
+            any = true;
+        }
+        if (any && sw.active && !sw.split) {
+            if (sw.sts.size() != s->n_workers) gather_states(*s, sw.sts);
+            rebalance_workers(*s, sw);   // parked workers and those of decided / withdrawn instances take them up
         }
         return 0;
     } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }

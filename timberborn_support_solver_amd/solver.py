@@ -39,7 +39,7 @@ class Mi355SatOpts(ctypes.Structure):
                 ("slice_conflicts", ctypes.c_int32), ("seed", ctypes.c_uint64), ("verbose", ctypes.c_int32),
                 ("reduce_first", ctypes.c_int32), ("reduce_inc", ctypes.c_int32), ("lds_val", ctypes.c_int32),
                 ("max_groups", ctypes.c_int32), ("slice_ms", ctypes.c_int32), ("cube_split", ctypes.c_int32), ("share", ctypes.c_int32), ("share_lbd", ctypes.c_int32), ("share_len", ctypes.c_int32),
-                ("share_interval", ctypes.c_int32), ("var_order", ctypes.c_int32), ("ramp", ctypes.c_int32), ("rebalance", ctypes.c_int32)]
+                ("share_interval", ctypes.c_int32), ("var_order", ctypes.c_int32), ("ramp", ctypes.c_int32), ("one_per_simd", ctypes.c_int32), ("rebalance", ctypes.c_int32)]
 
 
 class Mi355SatStats(ctypes.Structure):
@@ -85,6 +85,7 @@ def _bind(L):
     L.mi355sat_sweep_step.argtypes = [vp, vp, vp]
     L.mi355sat_sweep_end.argtypes = [vp]
     L.mi355sat_sweep_drop.argtypes = [vp, vp, ctypes.c_uint64]
+    L.mi355sat_sweep_reopen.argtypes = [vp, vp, ctypes.c_uint64]
     L.mi355sat_sweep_model_of.argtypes = [vp, ctypes.c_uint64, vp, ctypes.c_uint64]
     L.mi355sat_propagate_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, ctypes.c_int32]
     L.mi355sat_val.argtypes = [vp, ctypes.c_int32]
@@ -120,7 +121,7 @@ class Interrupter:
 
 class Mi355Sat:
     def __init__(self, device=-1, workers=0, conflict_budget=0, slice_conflicts=0, seed=0, verbose=0,
-                 reduce_first=0, reduce_inc=0, lds_val=0, max_groups=0, slice_ms=0, cube_split=0, share=0, share_lbd=0, share_len=0, share_interval=0, rebalance=0, var_order=0, ramp=0, _lib_override=None):
+                 reduce_first=0, reduce_inc=0, lds_val=0, max_groups=0, slice_ms=0, cube_split=0, share=0, share_lbd=0, share_len=0, share_interval=0, rebalance=0, var_order=0, ramp=0, one_per_simd=0, _lib_override=None):
         # _lib_override: test hook (the wavefront-emulator build under tests/emu); the product
         # always binds the HIP library and fails loudly without it.
         raw = _lib_override if _lib_override is not None else _lib.solver_lib()
@@ -129,7 +130,7 @@ class Mi355Sat:
         self._L = _bound[id(raw)]
         opts = Mi355SatOpts(device=device, workers=workers, conflict_budget=conflict_budget,
                             slice_conflicts=slice_conflicts, seed=seed, verbose=verbose,
-                            reduce_first=reduce_first, reduce_inc=reduce_inc, lds_val=lds_val, max_groups=max_groups, slice_ms=slice_ms, cube_split=cube_split, share=share, share_lbd=share_lbd, share_len=share_len, share_interval=share_interval, rebalance=rebalance, var_order=var_order, ramp=ramp)
+                            reduce_first=reduce_first, reduce_inc=reduce_inc, lds_val=lds_val, max_groups=max_groups, slice_ms=slice_ms, cube_split=cube_split, share=share, share_lbd=share_lbd, share_len=share_len, share_interval=share_interval, rebalance=rebalance, var_order=var_order, ramp=ramp, one_per_simd=one_per_simd)
         self._h = self._L.mi355sat_new(ctypes.byref(opts))
         if not self._h:
             raise SolverError("mi355sat_new failed: " + (self._L.mi355sat_last_error(None) or b"").decode())
@@ -209,6 +210,12 @@ class Mi355Sat:
         idx = np.asarray(list(instances), dtype=np.uint64)
         if len(idx):
             self._check(self._L.mi355sat_sweep_drop(self._h, _p(idx), len(idx)), "sweep_drop")
+
+    def sweep_reopen(self, instances):
+        """Take withdrawn, still undecided instances up again (idle workers move to them)."""
+        idx = np.asarray(list(instances), dtype=np.uint64)
+        if len(idx):
+            self._check(self._L.mi355sat_sweep_reopen(self._h, _p(idx), len(idx)), "sweep_reopen")
 
     def sweep_solution_of(self, instance, n_vars=None):
         """Model of an instance that already reported Sat, while the sweep is running."""
