@@ -30,6 +30,36 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _cpu_leg(job):
+    """One process of the all-cores CPU baseline: the oracle's CDCL on one (k) instance for a conflict budget."""
+    lits, offs, assumps, budget = job
+    from oracle import oracle as ora
+    o = ora.OracleSolver()
+    o.add_cnf(lits, offs)
+    o.solve(assumps, conflict_budget=budget)
+    st = o.stats()
+    return st["propagations"], st["conflicts"]
+
+
+def measured_copy_gbs(torch, device_index):
+    """Streaming ceiling measured on this box: device-to-device copy of 2 GiB (read + write = 4 GiB of traffic)."""
+    n = 1 << 29
+    a = torch.empty(n, dtype=torch.int32, device=f"cuda:{device_index}")
+    b = torch.empty_like(a)
+    a.fill_(1)
+    best = 0.0
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,8 +73,11 @@ def main():
     ap.add_argument("--cpu-conflicts", type=int, default=200000, help="conflict budget of the CPU baseline sample (~10-15 s)")
     ap.add_argument("--first-unsat-size", type=int, default=24, help="rect size of the wall-clock-to-first-UNSAT rung (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the all-cores CPU leg (0 = all host cores)")
     ap.add_argument("--var-order", type=int, default=0, help="0 caller's numbering (default), 1 locality order (A/B)")
-    ap.add_argument("--share", type=int, default=0, help="0 learnt-clause exchange on (default), -1 off (A/B)")
+    ap.add_argument("--share", type=int, default=-1, help="learnt-clause exchange in the THROUGHPUT sweep: -1 off (default: the "
+                    "exchange makes the trajectory, and with it the rate, depend on slice timing), 0 on.  The first-UNSAT line always "
+                    "runs the product default (exchange on).")
     ap.add_argument("--platforms", default="default", choices=["default", "1x1"])
     args = ap.parse_args()
 
@@ -115,12 +148,17 @@ def main():
     barrier()
     t0 = time.perf_counter()
     decided = 0
+    marks = [(t0, st0["propagations"])]          # per-step stamps: the spread of the rate inside the timed region
     for _ in range(args.steps):
         res, decided = solver.sweep_step()
         cut = exchange_cut(res)
+        marks.append((time.perf_counter(), solver.stats()["propagations"]))
     barrier()
     dt = time.perf_counter() - t0
     st1 = solver.stats()
+    n_win = 3 if args.steps >= 3 else 1
+    edges = [round(i * args.steps / n_win) for i in range(n_win + 1)]
+    win = [(marks[b][1] - marks[a][1]) / max(marks[b][0] - marks[a][0], 1e-9) for a, b in zip(edges[:-1], edges[1:])]
 
     d = {k: st1[k] - st0[k] for k in ("propagations", "conflicts", "decisions", "n_deq", "n_watch", "n_cl_lit",
                                       "n_move", "n_enq", "kernel_seconds", "kernel_launches")}
@@ -137,7 +175,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:   # reported baseline: rank 0 at N=1 only
+        import numpy as np
         from oracle import oracle as ora
+        np_lits, np_offs = np.asarray(cnf.lits, dtype=np.int32), np.asarray(cnf.offsets, dtype=np.uint64)
         o = ora.OracleSolver()
         o.add_cnf(cnf.lits, cnf.offsets)
         k_cpu = ks[-1]
@@ -149,6 +189,18 @@ def main():
                "sample": f"rect {n}x{n} {args.platforms}, at-most-{k_cpu}, first {so['conflicts']} conflicts "
                          f"({dtc:.1f} s) of the oracle's single-thread CDCL restatement (not rustsat-glucose)",
                "conflicts_per_s": so["conflicts"] / max(dtc, 1e-9)}
+        # all host cores, one independent (k) instance per core, same conflict budget each
+        import multiprocessing as mp
+        ncores = min(os.cpu_count() or 1, args.cpu_cores) if args.cpu_cores > 0 else (os.cpu_count() or 1)
+        jobs = [(np_lits, np_offs, assumption_sets[i % len(ks)], args.cpu_conflicts) for i in range(ncores)]
+        tc = time.perf_counter()
+        with mp.get_context("fork").Pool(ncores) as pool:
+            rs = pool.map(_cpu_leg, jobs)
+        dta = time.perf_counter() - tc
+        cpu["all_cores"] = {"value": sum(r[0] for r in rs) / max(dta, 1e-9), "unit": "propagations/s", "cores": ncores,
+                            "conflicts_per_s": sum(r[1] for r in rs) / max(dta, 1e-9),
+                            "sample": f"{ncores} processes, one at-most-k instance each (k cycling {ks[0]}..{ks[-1]}), "
+                                      f"{args.cpu_conflicts} conflicts each, {dta:.1f} s wall"}
 
     solver.sweep_end()
     solver.close()
@@ -158,6 +210,27 @@ def main():
     # then every lower bound as one batch until max UNSAT k + 1 == min count).  CPU: the reference's
     # sequential loop (k := count - 1) on the oracle.
     first_unsat = None
+    sharded = None
+    if world > 1 and args.first_unsat_size > 0:
+        # strong scaling of ONE ladder over the ranks: the bounds k = k_hi - rank - i*world are sharded, the cut
+        # (min SAT count, max UNSAT k) and the best model are the only things exchanged
+        from timberborn_support_solver_amd.sweep import solver_loop_sweep_sharded
+        m = args.first_unsat_size
+        g2 = WorldGrid.rect(m, m)
+        e2 = Encoding.encode(defs, g2)
+        st_sh = {}
+        barrier()
+        tg = time.perf_counter()
+        hist = solver_loop_sweep_sharded(g2, e2, PlatformLimits({(1, 1): max(4, m * m // 24)}), out=lambda line: None, time_limit=120,
+                                         make_solver=lambda: Mi355Sat(device=device_index, slice_ms=10, seed=1000 + rank),
+                                         device=coll_dev, stats_out=st_sh)
+        barrier()
+        gpu_s = time.perf_counter() - tg
+        sat = [h for h in hist if h["result"] == SolverResult.Sat]
+        ok = bool(sat) and hist[-1]["result"] == SolverResult.Unsat and all(h["valid"] for h in sat)
+        sharded = {"instance": f"rect {m} {m} {args.platforms}, solver_loop_sweep_sharded over {world} ranks",
+                   "optimum_k": sat[-1]["count"] if ok else None, "gpu_seconds": gpu_s if ok else None,
+                   "seconds_to_cut_after_first_bound": st_sh.get("seconds_to_cut")}
     if rank == 0 and world == 1 and args.first_unsat_size > 0 and not args.no_cpu:
         from oracle import oracle as ora
         from timberborn_support_solver_amd import PlatformLayout
@@ -196,6 +269,7 @@ def main():
         kern_s = d["kernel_seconds"]
         launches = max(1, d["kernel_launches"])
         achieved = alg_bytes / max(kern_s, 1e-9) / 1e9
+        peak_measured = measured_copy_gbs(torch, device_index)
         # HBM bytes per launch of the dominant kernel from the PMC passes (they cannot run inside this process:
         # separate `rocprofv3 --pmc` runs of this same command; the committed summary is attached when this run is
         # the configuration it was taken on)
@@ -203,7 +277,7 @@ def main():
         import glob
         tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
         default_cfg = (n == 64 and args.k_lo == 44 and args.k_hi == 51 and workers == 4096 and args.slice_ms == 250 and
-                       args.platforms == "default" and args.share == 0 and args.var_order == 0)
+                       args.platforms == "default" and args.share == -1 and args.var_order == 0)
         if tfiles and default_cfg:
             tj = json.load(open(tfiles[-1]))
             traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/" + os.path.basename(tfiles[-1])
@@ -224,13 +298,21 @@ def main():
                                    f"{args.platforms} platforms, one totalizer CNF shared by all k",
                        "vars": int(cnf.n_vars), "clauses": int(cnf.n_clauses), "literals": int(len(cnf.lits)),
                        "workers_per_gpu": workers, "instances_per_gpu": len(ks), "slice_ms": args.slice_ms,
-                       "parallelism": f"{world} GPU(s) x {workers} wavefront workers, seeds sharded over ranks"},
+                       "exchange": ("off" if args.share < 0 else "on") + " in the throughput sweep (value); on in the first-UNSAT line",
+                       "parallelism": f"{world} GPU(s) x {workers} wavefront workers; value: seeds sharded over ranks (weak); "
+                                      f"first_unsat_sharded: bounds k = k_hi - rank - i*{world} of one ladder sharded (strong)"},
+            "windows": {"n": len(win), "values": win, "median": sorted(win)[len(win) // 2],
+                        "spread": (max(win) - min(win)) / max(sorted(win)[len(win) // 2], 1e-9),
+                        "note": "rank 0's rate in consecutive thirds of the timed region"},
             "conflicts_per_s": total_confl / max_dt,
             "decided_instances": int(decided),
             "first_unsat_wall_clock_s": first_unsat["gpu_seconds"] if first_unsat else None,
             "first_unsat": first_unsat,
+            "first_unsat_sharded": sharded,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "peak_measured": peak_measured,
+                         "peak_measured_note": "device-to-device copy of 2 GiB on this box (read + write bytes)",
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ms_search_kernel", "kernel_ms_avg": kern_s / launches * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "bytes_per_propagation": alg_bytes / max(1, props)},
