@@ -75,7 +75,7 @@ typedef struct mi355sat_opts {
     int32_t share;             /* learnt-clause exchange between the workers of one GPU (units, binaries and clauses of
                                   at most share_len literals with LBD <= share_lbd, passed on between kernel launches):
                                   0 = default (on), -1 = off.  Off automatically with one worker or a proof log. */
-    int32_t share_lbd;         /* 0 = 2 */
+    int32_t share_lbd;         /* 0 = 4 (measured: rect 24 k=8 1.0 vs 1.3 s, rect 16 1x1 k=14 14-18 vs 24 s with 2; 6-12 no better) */
     int32_t share_len;         /* longest exchanged clause, <= 31; 0 = 31 */
     int32_t share_interval;    /* > 0: a worker with unseen exchanged clauses restarts to attach them after this many of its
                                   own conflicts; 0 = default: only at its own (Glucose) restarts - forced restarts measured

@@ -59,15 +59,6 @@ typedef unsigned long long u64;
 #endif
 enum { PF_OFF = 0, PF_BIN, PF_TERN, PF_LONG, PF_CLOSE, PF_ANALYZE, PF_BACKJUMP, PF_DECIDE, PF_REDUCE, PF_N };
 
-#ifndef MS_MINIMIZE
-#define MS_MINIMIZE 1    // learnt-clause minimisation: 1 local (one reason deep), 2 recursive (lit_redundant)
-#endif
-#ifndef MS_BUMP_MODE
-#define MS_BUMP_MODE 0   // decision-queue bumping after a conflict, see analyze()
-#endif
-#ifndef MS_SPECULATE
-#define MS_SPECULATE 1   // load a watcher's clause header and watched pair together with its blocker's value
-#endif
 #define DEV __device__ __forceinline__
 // cold paths are real calls: keeps them out of the hot loop's register allocation
 #define DEV_COLD __device__ __noinline__
@@ -80,6 +71,7 @@ struct Wk {
     volatile uint32_t* ov_cnt;
     volatile uint32_t* hist;   // 64 words, reduce_db; also the scratch of flat_setup (BCP)
     volatile uint32_t* lval;   // packed assignment, 2 bits per variable (LV variants)
+    volatile uint32_t* lseen;  // conflict analysis' "seen" marks, 1 bit per variable (LV variants; all zero between analyses)
     volatile int32_t* bfl;     // the false literal of each lane group of the current BCP step
     // hot uniform scalars
     int lane;
@@ -154,6 +146,25 @@ DEV void asg_clear(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
     const uint32_t mask = ~(3u << ((v & 15) * 2));
     if (LV) atomicAnd((uint32_t*)&w.lval[v >> 4], mask);
     else __hip_atomic_fetch_and(WKA(uint32_t, val) + (v >> 4), mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- "seen" marks of conflict analysis ----------------------------------------------------
+// LV: one bit per variable in LDS (a trail walk tests 64 entries at once without touching HBM); otherwise the
+// byte in the variable's record.
+template <bool LV>
+DEV bool seen_get(const Wk& w, const MsShared& sh, const MsLayout& L, int v) {
+    if (LV) return (w.lseen[v >> 5] >> (v & 31)) & 1u;
+    return VREC[v].seen != 0;
+}
+template <bool LV>
+DEV void seen_set(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
+    if (LV) atomicOr((uint32_t*)&w.lseen[v >> 5], 1u << (v & 31));
+    else VREC[v].seen = 1;
+}
+template <bool LV>
+DEV void seen_clr(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
+    if (LV) atomicAnd((uint32_t*)&w.lseen[v >> 5], ~(1u << (v & 31)));
+    else VREC[v].seen = 0;
 }
 
 DEV void clause_range(const Wk& w, const MsShared& sh, const MsLayout& L, int c, const int32_t*& lits, int& size) {
@@ -246,12 +257,20 @@ DEV void commit_implications(Wk& w, const MsShared& sh, const MsLayout& L, bool 
     lds_fence();
 }
 
+DEV MsClauseHdr clause_hdr_of(const Wk& w, const MsShared& sh, const MsLayout& L, int c) {
+    const MsClauseRec h = WKA(MsClauseRec, wl)[c];
+    return MsClauseHdr{h.start, h.size};
+}
+
 // ---- watch lists -------------------------------------------------------
+// A watcher is 16 bytes: {cref, blocker, start, size} - where the clause's literals are travels with it, so a
+// visit whose blocker is not true fetches the clause's watched pair (wl[cref]) and its first literals in ONE round
+// trip instead of two dependent ones.
 // Append (cref, blocker) to the list of literal t (uniform call, rare path:
 // learnt clause attach and overflow repair).  Grows the list from the bump pool.
-DEV bool list_push_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int t, int cref, int blocker) {
+DEV bool list_push_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int t, int cref, int blocker, uint32_t start, uint32_t size) {
     MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
-    int2* pool = WKA(int2, pool);
+    int4* pool = WKA(int4, pool);
     uint32_t s = (uint32_t)uni((int)whdr[t].size);
     uint32_t cap = (uint32_t)uni((int)whdr[t].cap);
     if (s > cap) s = cap;  // overshoot left by failed atomic pushes
@@ -266,7 +285,7 @@ DEV bool list_push_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int t, 
         if (w.lane == 0) { whdr[t].base = nb; whdr[t].cap = ncap; }
         base = nb;
     }
-    if (w.lane == 0) { pool[base + s] = make_int2(cref, blocker); whdr[t].size = s + 1; }
+    if (w.lane == 0) { pool[base + s] = make_int4(cref, blocker, (int)start, (int)size); whdr[t].size = s + 1; }
     wave_fence();
     return true;
 }
@@ -278,7 +297,8 @@ DEV void repair_overflow(Wk& w, const MsShared& sh, const MsLayout& L) {
     const int32_t* ov = WK_PTR(int32_t, w, L, overflow);
     for (uint32_t e = 0; e < n && w.status == MS_ST_RUNNING; e++) {
         int t = uni(ov[3 * e]), c = uni(ov[3 * e + 1]), b = uni(ov[3 * e + 2]);
-        list_push_uniform(w, sh, L, t, c, b);
+        const MsClauseHdr h = clause_hdr_of(w, sh, L, c);
+        list_push_uniform(w, sh, L, t, c, b, (uint32_t)uni((int)h.start), (uint32_t)uni((int)h.size));
     }
     if (w.lane == 0) *w.ov_cnt = 0;
     lds_fence();
@@ -289,23 +309,17 @@ DEV void repair_overflow(Wk& w, const MsShared& sh, const MsLayout& L) {
 #define MS_LANE_SCAN 8   // clause literals the visiting lane examines itself (multiple of 4)
 #endif
 struct LongRes {
-    int2 wt;            // watcher to keep (blocker possibly updated)
+    int4 wt;            // watcher to keep (blocker possibly updated)
     bool live, keep, want, cf, deferred;
     int imp;            // implied literal if want
 };
 
-DEV MsClauseHdr clause_hdr_of(const Wk& w, const MsShared& sh, const MsLayout& L, int c) {
-    const MsClauseRec h = WKA(MsClauseRec, wl)[c];
-    return MsClauseHdr{h.start, h.size};
-}
-
-// Visit watcher `wt` of the false literal `fl`.  vbl / ww / ch are the blocker's value, the clause's
-// watched pair and its header, loaded speculatively by the caller together with everything else the
-// step needs (one round trip).  All values are a snapshot taken before the step's commit.  Must be
-// called by all 64 lanes (phase B is wave-cooperative).
+// Visit watcher `wt` of the false literal `fl`.  vbl / ww are the blocker's value and the clause's
+// watched pair, loaded by the caller together with everything else the step needs.  All values are a
+// snapshot taken before the step's commit.  Must be called by all 64 lanes (phase B is wave-cooperative).
 template <bool LV>
-DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, bool live, int vbl, int2 ww, MsClauseHdr ch,
-                      int fl, int g) {
+DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, bool live, int vbl, int2 ww, int fl, int g) {
+    const MsClauseHdr ch = MsClauseHdr{(uint32_t)wt.z, (uint32_t)wt.w};
     LongRes R;
     R.wt = wt; R.live = live; R.keep = live; R.want = false; R.cf = false; R.deferred = false; R.imp = 0;
     bool scanning = false, need_tail = false;
@@ -314,15 +328,6 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
     const int32_t* cl = ((uint32_t)wt.x < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + ch.start;
     uint32_t nl = 0;
     if (live && vbl != MS_VAL_TRUE) {
-#if !MS_SPECULATE
-        {   // only for watchers whose blocker is not true (one more round trip, one line less per satisfied watcher)
-            const MsClauseRec cr = WKA(MsClauseRec, wl)[wt.x];
-            ww = make_int2(cr.w0, cr.w1);
-            ch = MsClauseHdr{cr.start, cr.size};
-        }
-        size = (int)ch.size;
-        cl = ((uint32_t)wt.x < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + ch.start;
-#endif
         other = (ww.x == fl) ? ww.y : ww.x;
         // the other watch and the first MS_LANE_SCAN literals (16-byte loads) + their values, issued together
         int ls[MS_LANE_SCAN], vs[MS_LANE_SCAN];
@@ -379,7 +384,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int2 wt, boo
             const int t = r ^ 1;
             const uint32_t pos = atomicAdd(&whdr[t].size, 1u);
             const uint32_t tbase = whdr[t].base, tcap = whdr[t].cap;
-            if (pos < tcap) WKA(int2, pool)[tbase + pos] = R.wt;
+            if (pos < tcap) WKA(int4, pool)[tbase + pos] = R.wt;
             else {
                 uint32_t o = atomicAdd((uint32_t*)w.ov_cnt, 1u);
                 int32_t* ov = WK_PTR(int32_t, w, L, overflow);
@@ -427,7 +432,7 @@ template <bool LV>
 DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
     w.confl_kind = 0;
     MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
-    int2* pool = WKA(int2, pool);
+    int4* pool = WKA(int4, pool);
     const MsClauseRec* wl = WKA(MsClauseRec, wl);
     const int32_t* trail = WKA(int32_t, trail);
     while (w.qhead < w.trail_n && w.status == MS_ST_RUNNING) {
@@ -451,28 +456,22 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const bool act_b = (uint32_t)sl < nb, act_t = (uint32_t)sl < nt;
         const int q0 = act_b ? sh.bin_lits[b0 + sl] : 0;
         const int2 pr0 = act_t ? ((const int2*)sh.tern_pairs)[t0 + sl] : make_int2(0, 0);
-        const int2 wt0 = sl < n ? pool[wb + sl] : make_int2(-1, 0);
+        const int4 wt0 = sl < n ? pool[wb + sl] : make_int4(-1, 0, 0, 0);
         w.qhead += G;
         w.c_props += (uint32_t)G;
         w.c_steps++;
         // the false literals of all groups of this step (LDS), for the clash test in long_eval
         if (sl == 0) w.bfl[g] = fl;
         lds_fence();
-        // round trip 2: ONE snapshot of every value the first chunks need, plus (speculatively) the
-        // watched pair and the header of every live watcher's clause
+        // round trip 2: ONE snapshot of every value the first chunks need, plus the watched pair of the clauses
+        // whose blocker is not true (assignment in LDS: the blockers' values are known at once) or, with the
+        // assignment in HBM, speculatively of every live watcher's clause
         const bool live0 = sl < n && wt0.x >= 0;
         const int vq = act_b ? lit_value<LV>(w, sh, L, q0) : MS_VAL_TRUE;
         const int vb = act_t ? lit_value<LV>(w, sh, L, pr0.x) : MS_VAL_TRUE;
         const int vc = act_t ? lit_value<LV>(w, sh, L, pr0.y) : MS_VAL_TRUE;
         const int vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
-#if MS_SPECULATE
-        const MsClauseRec cr0 = live0 ? wl[wt0.x] : MsClauseRec{0, 0, 0, 0};
-        const int2 ww0 = make_int2(cr0.w0, cr0.w1);
-        const MsClauseHdr ch0 = MsClauseHdr{cr0.start, cr0.size};
-#else
-        const int2 ww0 = make_int2(0, 0);
-        const MsClauseHdr ch0 = MsClauseHdr{0, 0};
-#endif
+        const int2 ww0 = (live0 && (!LV || vbl0 != MS_VAL_TRUE)) ? *(const int2*)&wl[wt0.x] : make_int2(0, 0);
         PROF_MARK(PF_OFF);
         // evaluate binary + ternary entries on the snapshot
         const bool cf_b = vq == MS_VAL_FALSE, want_b = vq == MS_VAL_UNDEF;
@@ -484,7 +483,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         PROF_MARK(PF_BIN);
         // first chunk of the watch lists (round trips 3..: other watch + clause literals, pushes)
         int j = 0, done = 0, defer_g = MS_MAX_GROUPS;
-        LongRes R0 = long_eval<LV>(w, sh, L, wt0, live0, vbl0, ww0, ch0, fl, g);
+        LongRes R0 = long_eval<LV>(w, sh, L, wt0, live0, vbl0, ww0, fl, g);
         PROF_MARK(PF_LONG);
         // ONE commit for the whole first chunk: binary, ternary and watched-clause implications
         bool any_cf;
@@ -592,19 +591,12 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
             for (int i0 = S; i0 < n_l && !any_cf && w.status == MS_ST_RUNNING; i0 += MS_WAVE) {
                 const int i = i0 + w.lane;
                 const bool act = i < n_l;
-                const int2 wt = act ? pool[wb_l + i] : make_int2(-1, 0);
+                const int4 wt = act ? pool[wb_l + i] : make_int4(-1, 0, 0, 0);
                 const bool live = act && wt.x >= 0;
                 const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
-#if MS_SPECULATE
-                const MsClauseRec cr = live ? wl[wt.x] : MsClauseRec{0, 0, 0, 0};
-                const int2 ww = make_int2(cr.w0, cr.w1);
-                const MsClauseHdr ch = MsClauseHdr{cr.start, cr.size};
-#else
-                const int2 ww = make_int2(0, 0);
-                const MsClauseHdr ch = MsClauseHdr{0, 0};
-#endif
+                const int2 ww = (live && (!LV || vbl != MS_VAL_TRUE)) ? *(const int2*)&wl[wt.x] : make_int2(0, 0);
                 w.c_watch += (uint32_t)popc64(ballot(live));
-                LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, ch, fl_l, gl);
+                LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, fl_l, gl);
                 w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
                 const u64 km = ballot(R.keep);
                 wave_fence();
@@ -632,7 +624,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         if (done == n) {
             if (sl == 0 && n > 0 && j != n) whdr[p].size = (uint32_t)j;
         } else {
-            for (int x = j + sl; x < done; x += S) pool[wb + x] = make_int2(-1, 0);
+            for (int x = j + sl; x < done; x += S) pool[wb + x] = make_int4(-1, 0, 0, 0);
         }
         wave_fence();
         PROF_MARK(PF_CLOSE);
@@ -730,96 +722,20 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
 // ---- conflict analysis (first UIP) -----------------------------------------
 struct Learnt { int n, bt_level; uint32_t lbd; };
 
-// ---- recursive clause minimisation (MiniSat's litRedundant, one learnt literal per lane) ----------
-// q (false, with a reason) can be dropped from the learnt clause if every other literal of its reason is in
-// the clause, fixed at level 0, or itself implied by the clause in this sense.  Each lane walks the
-// implication graph of its own literal depth-first with a small private stack; what it proves about a
-// variable either way is memoised in the variable's record under this conflict's stamp, so lanes profit
-// from each other (the facts do not depend on who finds them; reasons point backwards on the trail, so
-// there are no cycles).  Literals at decision levels the clause does not touch cannot be implied by it
-// (abstract-level filter).  Too deep a walk gives up (keeps the literal).
-#ifndef MS_MIN_BUDGET
-#define MS_MIN_BUDGET 64     // reason literals one lane may inspect for its clause literal
-#endif
-#define MS_MIN_DEPTH 16
-struct MinFrame {
-    int var, n, idx;
-    int l0, l1, l2;          // binary / ternary reason: its literals
-    const int32_t* cl;       // long reason: its literal array
-};
-DEV void min_open(const Wk& w, const MsShared& sh, const MsLayout& L, MinFrame& f, int var, int r) {
-    f.var = var; f.idx = 0; f.cl = nullptr; f.l0 = f.l1 = f.l2 = 0;
-    if (r >= 0) {
-        const MsClauseHdr ch = clause_hdr_of(w, sh, L, r);
-        f.n = (int)ch.size;
-        f.cl = ((uint32_t)r < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + ch.start;
-    } else if (MS_IS_TERN_REASON(r)) {
-        const int e = MS_TERN_REASON_ENTRY(r);
-        const int2 pr = ((const int2*)sh.tern_pairs)[e];
-        f.n = 3; f.l0 = sh.tern_owner[e] ^ 1; f.l1 = pr.x; f.l2 = pr.y;
-    } else {
-        f.n = 1; f.l0 = MS_BIN_REASON_LIT(r);
-    }
-}
-DEV bool lit_redundant(Wk& w, const MsShared& sh, const MsLayout& L, int q, uint32_t abs_levels, uint32_t stamp) {
-    MsVarRec* vrec = VREC;
-    MinFrame st[MS_MIN_DEPTH];
-    int sp = 0, budget = MS_MIN_BUDGET;
-    {
-        const int r = vrec[q >> 1].reason;
-        if (r == MS_REASON_NONE) return false;
-        min_open(w, sh, L, st[0], q >> 1, r);
-    }
-    for (;;) {
-        MinFrame& f = st[sp];
-        bool failed = false, descended = false;
-        while (f.idx < f.n) {
-            const int k = f.idx++;
-            const int y = (f.cl ? f.cl[k] : (k == 0 ? f.l0 : (k == 1 ? f.l1 : f.l2))) >> 1;
-            if (y == f.var) continue;
-            const MsVarRec yr = vrec[y];
-            if (yr.level == 0 || yr.seen) continue;                       // fixed, or in the clause
-            if ((uint32_t)(yr.mstamp >> 2) == stamp) {                    // settled earlier in this conflict
-                if ((yr.mstamp & 3) == 2) continue;
-                failed = true;
-                break;
-            }
-            if (yr.reason == MS_REASON_NONE || !((abs_levels >> (yr.level & 31)) & 1u)) {
-                vrec[y].mstamp = (uint16_t)(stamp << 2 | 3u);
-                failed = true;
-                break;
-            }
-            if (sp + 1 == MS_MIN_DEPTH || --budget <= 0) { failed = true; break; }   // give up: nothing learnt about y
-            sp++;
-            min_open(w, sh, L, st[sp], y, yr.reason);
-            descended = true;
-            break;
-        }
-        if (failed) {   // every variable on the path needs a literal the clause does not imply
-            if (budget > 0 && sp + 1 < MS_MIN_DEPTH)
-                for (int i = 1; i <= sp; i++) vrec[st[i].var].mstamp = (uint16_t)(stamp << 2 | 3u);
-            return false;
-        }
-        if (descended) continue;
-        if (sp == 0) return true;
-        vrec[f.var].mstamp = (uint16_t)(stamp << 2 | 2u);
-        sp--;
-    }
-}
-
+template <bool LV>
 DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, MsVarRec* vrec, int32_t* toclear, int32_t* learnt_buf, bool act, int q, int dl,
                        int& path_c, int& n_out, int& n_clear) {
     int v = q >> 1;
     bool fresh = false, cur = false;
-    if (act) {
-        int lv = VREC[v].level;
-        fresh = !vrec[v].seen && lv > 0;
-        cur = fresh && lv >= dl;
+    if (act && !(LV && seen_get<LV>(w, sh, L, v))) {
+        const MsVarRec vr = vrec[v];
+        fresh = (LV || !vr.seen) && vr.level > 0;
+        cur = fresh && vr.level >= dl;
     }
     u64 fm = ballot(fresh), cm = ballot(cur);
     u64 lm = fm & ~cm;
     if (fresh) {
-        vrec[v].seen = 1;
+        seen_set<LV>(w, sh, L, v);
         toclear[n_clear + popc64(fm & lanemask_lt(w.lane))] = v;
         if (!cur) learnt_buf[n_out + popc64(lm & lanemask_lt(w.lane))] = q;
     }
@@ -828,6 +744,7 @@ DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, MsVarRec* v
     path_c += popc64(cm);
 }
 
+template <bool LV>
 DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp) {
     MsVarRec* vrec = VREC;
     int32_t* toclear = WK_PTR(int32_t, w, L, toclear);
@@ -835,6 +752,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
     int path_c = 0, p = -1, n_out = 1, n_clear = 0;
     int index = w.trail_n - 1;
+    int chunk_hi = -1, chunk_l = 0;   // cached chunk of the trail (LV)
     const int dl = w.n_levels;
     int kind = w.confl_kind, cref = w.confl_cref, ba = w.confl_a, bb = w.confl_b, bc = w.confl_c;
     for (;;) {
@@ -846,36 +764,61 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
             for (int k0 = 0; k0 < size; k0 += MS_WAVE) {
                 int k = k0 + w.lane;
                 int q = k < size ? cl[k] : 0;
-                analyze_visit(w, sh, L, vrec, toclear, learnt_buf, k < size && q != p, q, dl, path_c, n_out, n_clear);
+                analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, k < size && q != p, q, dl, path_c, n_out, n_clear);
             }
         } else {
             int q = w.lane == 0 ? ba : (w.lane == 1 ? bb : bc);
-            analyze_visit(w, sh, L, vrec, toclear, learnt_buf, w.lane < kind && q != p, q, dl, path_c, n_out, n_clear);
+            analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, w.lane < kind && q != p, q, dl, path_c, n_out, n_clear);
         }
         wave_fence();
-        // walk the trail back to the most recent literal marked seen: 16 entries first (each costs a random
-        // variable-record line and the next one is usually close), the whole wave only when those miss
-        for (int width = 16;; width = MS_WAVE) {
-            int i = index - w.lane;
-            const bool in = w.lane < width && i >= 0;
-            int l = in ? WKA(int32_t, trail)[i] : 0;
-            bool ok = in && vrec[l >> 1].seen;
-            u64 m = ballot(ok);
-            if (m) {
-                int f = first_lane(m);
-                index -= f;
-                p = bcast(l, f);
-                break;
+        if (LV) {
+            // walk the trail back to the most recent literal marked seen.  The marks are in LDS, so a chunk of 64
+            // trail entries (one coalesced load, lane i holds position chunk_hi - i) is tested at once and is kept
+            // in registers across resolution steps until the walk leaves it.
+            lds_fence();
+            for (;;) {
+                if (chunk_hi < 0 || index > chunk_hi || index <= chunk_hi - MS_WAVE) {
+                    chunk_hi = index;
+                    const int i = chunk_hi - w.lane;
+                    chunk_l = i >= 0 ? WKA(int32_t, trail)[i] : 0;
+                }
+                const int pos = chunk_hi - w.lane;
+                const bool ok = pos >= 0 && pos <= index && seen_get<LV>(w, sh, L, chunk_l >> 1);
+                const u64 m = ballot(ok);
+                if (m) {
+                    const int f = first_lane(m);
+                    index = chunk_hi - f;
+                    p = bcast(chunk_l, f);
+                    break;
+                }
+                index = chunk_hi - MS_WAVE;
+                if (index < 0) { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
             }
-            index -= width;
-            if (index < 0) { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
+        } else {
+            // 16 entries first (each costs a random variable-record line and the next one is usually close), the
+            // whole wave only when those miss
+            for (int width = 16;; width = MS_WAVE) {
+                int i = index - w.lane;
+                const bool in = w.lane < width && i >= 0;
+                int l = in ? WKA(int32_t, trail)[i] : 0;
+                bool ok = in && vrec[l >> 1].seen;
+                u64 m = ballot(ok);
+                if (m) {
+                    int f = first_lane(m);
+                    index -= f;
+                    p = bcast(l, f);
+                    break;
+                }
+                index -= width;
+                if (index < 0) { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
+            }
         }
         index--;
         const int v = p >> 1;
         const int r = uni(VREC[v].reason);
         wave_fence();
-        if (w.lane == 0) vrec[v].seen = 0;
-        wave_fence();
+        if (w.lane == 0) seen_clr<LV>(w, sh, L, v);
+        lds_fence();
         path_c--;
         if (path_c <= 0) break;
         if (r >= 0) { kind = 1; cref = r; }
@@ -890,62 +833,35 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     wave_fence();
     if (w.lane == 0) learnt_buf[0] = p ^ 1;
     wave_fence();
-#if MS_MINIMIZE == 2
-    // ---- recursive minimisation (see lit_redundant).  Measured on MI355X: learnt clauses 150 -> 65 literals on
-    // the rect 20/24 rungs, but no consistent gain in conflicts to a verdict there and 11 % fewer propagations/s
-    // on the 64x64 sweep (8 % with MS_MIN_BUDGET=8) - so the default stays the one-reason-deep version below.
-    if (stamp == 0)   // the 14-bit stamp wrapped: forget every memo
-        for (uint32_t v = (uint32_t)w.lane; v < sh.n_vars; v += MS_WAVE) vrec[v].mstamp = 0;
-    uint32_t abs_levels = 0;
-    for (int i = 1 + w.lane; i < n_out; i += MS_WAVE) abs_levels |= 1u << (VREC[learnt_buf[i] >> 1].level & 31);
-    for (int o = 32; o > 0; o >>= 1) abs_levels |= (uint32_t)__shfl_xor((int)abs_levels, o, 64);
-    wave_fence();
-    int j = 1;
-    for (int i0 = 1; i0 < n_out; i0 += MS_WAVE) {
-        int i = i0 + w.lane;
-        bool act = i < n_out, keep = act;
-        int q = act ? learnt_buf[i] : 0;
-        if (act) keep = !lit_redundant(w, sh, L, q, abs_levels, stamp);
-        u64 km = ballot(keep);
-        wave_fence();
-        if (keep) learnt_buf[j + popc64(km & lanemask_lt(w.lane))] = q;
-        j += popc64(km);
-        wave_fence();
-    }
-#else
-    // ---- local minimisation: drop a literal whose reason's other literals are all seen / level 0
+    // ---- local minimisation: drop a literal whose reason's other literals are all seen / level 0.
+    // One learnt literal per lane; a long reason is read four literals per load (clauses start 16-byte aligned)
+    // and a literal's level is only fetched when it is not marked.
     int j = 1;
     for (int i0 = 1; i0 < n_out; i0 += MS_WAVE) {
         int i = i0 + w.lane;
         bool act = i < n_out, keep = act;
         int q = act ? learnt_buf[i] : 0;
         if (act) {
-            int r = VREC[q >> 1].reason;
+            const int qv = q >> 1;
+            int r = VREC[qv].reason;
+            auto implied = [&](int l) { return (l >> 1) == qv || seen_get<LV>(w, sh, L, l >> 1) || VREC[l >> 1].level == 0; };
             if (r >= 0) {
                 const int32_t* cl;
                 int size;
                 clause_range(w, sh, L, r, cl, size);
                 bool red = true;
-                for (int k = 0; k < size && red; k++) {
-                    int l = cl[k];
-                    if ((l >> 1) == (q >> 1)) continue;
-                    red = vrec[l >> 1].seen || VREC[l >> 1].level == 0;
+                for (int k = 0; k < size && red; k += 4) {
+                    const int4 q4 = *(const int4*)(cl + k);
+                    red = implied(q4.x) && (k + 1 >= size || implied(q4.y)) && (k + 2 >= size || implied(q4.z)) &&
+                          (k + 3 >= size || implied(q4.w));
                 }
                 keep = !red;
             } else if (MS_IS_TERN_REASON(r)) {
                 const int e = MS_TERN_REASON_ENTRY(r);
                 const int2 pr = ((const int2*)sh.tern_pairs)[e];
-                const int l3[3] = {sh.tern_owner[e] ^ 1, pr.x, pr.y};
-                bool red = true;
-                for (int k = 0; k < 3; k++) {
-                    int l = l3[k];
-                    if ((l >> 1) == (q >> 1)) continue;
-                    red = red && (vrec[l >> 1].seen || VREC[l >> 1].level == 0);
-                }
-                keep = !red;
+                keep = !(implied(sh.tern_owner[e] ^ 1) && implied(pr.x) && implied(pr.y));
             } else if (MS_IS_BIN_REASON(r)) {
-                int l = MS_BIN_REASON_LIT(r);
-                keep = !(vrec[l >> 1].seen || VREC[l >> 1].level == 0);
+                keep = !implied(MS_BIN_REASON_LIT(r));
             }
         }
         u64 km = ballot(keep);
@@ -954,7 +870,6 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
         j += popc64(km);
         wave_fence();
     }
-#endif
     n_out = j;
     // ---- backjump level = max level among learnt_buf[1..), moved to position 1
     int bt = 0;
@@ -1000,52 +915,21 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
         }
         w.lvl_stamp_ctr = nb;
     }
-    // ---- clear marks and bump variables to the front of the queue (MS_BUMP_MODE: which, in what order)
+    // ---- clear marks and bump the analysed variables to the front of the queue, in the order analysis met them
+    // (measured in round 1: reversed order 3-7e4 conflicts per worker on the rect 20/24 rungs instead of 1-2e4, only
+    // the learnt clause's variables 7-13e4, by previous queue position like this order)
     if (w.vm_end + n_clear > (int)L.vm_cap) vm_compact(w, sh, L);
     {
         int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
-#if MS_BUMP_MODE == 2
-        // only the variables of the learnt clause, the asserting literal last (= first to be decided)
-        for (int i = w.lane; i < n_clear; i += MS_WAVE) vrec[toclear[i]].seen = 0;
-        wave_fence();
-        for (int i = w.lane; i < n_out; i += MS_WAVE) {
-            int v = learnt_buf[i] >> 1;
-            vm_order[w.vm_end + (n_out - 1 - i)] = v;
-            vrec[v].vm_pos = w.vm_end + (n_out - 1 - i);
-        }
-        w.vm_end += n_out;
-#elif MS_BUMP_MODE == 3
-        // every analysed variable, keeping their previous relative order (rank by old queue position)
-        uint32_t* key = WK_PTR(uint32_t, w, L, remap);   // scratch outside reduce_db
-        const bool ranked = n_clear <= 1024 && (uint32_t)n_clear <= L.learnt_cap;
-        if (ranked) {
-            for (int i = w.lane; i < n_clear; i += MS_WAVE) key[i] = (uint32_t)vrec[toclear[i]].vm_pos;
-            wave_fence();
-        }
         for (int i = w.lane; i < n_clear; i += MS_WAVE) {
             int v = toclear[i];
-            int r = i;
-            if (ranked) {
-                const uint32_t ki = key[i];
-                r = 0;
-                for (int j = 0; j < n_clear; j++) r += key[j] < ki;
-            }
-            vrec[v].seen = 0;
-            vm_order[w.vm_end + r] = v;
-            vrec[v].vm_pos = w.vm_end + r;
+            seen_clr<LV>(w, sh, L, v);
+            vm_order[w.vm_end + i] = v;
+            vrec[v].vm_pos = w.vm_end + i;
         }
         w.vm_end += n_clear;
-#else
-        for (int i = w.lane; i < n_clear; i += MS_WAVE) {
-            int v = toclear[i];
-            const int d = MS_BUMP_MODE == 1 ? n_clear - 1 - i : i;   // 0: in the order analysis met them, 1: reversed
-            vrec[v].seen = 0;
-            vm_order[w.vm_end + d] = v;
-            vrec[v].vm_pos = w.vm_end + d;
-        }
-        w.vm_end += n_clear;
-#endif
     }
+    lds_fence();
     wave_fence();
     return Learnt{n_out, bt, lbd};
 }
@@ -1057,7 +941,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
 // over the 2*n_vars lists (wave prefix sums), fill.  Runs at a propagation fixpoint.
 DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
     MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
-    int2* pool = WKA(int2, pool);
+    int4* pool = WKA(int4, pool);
     const MsClauseRec* wl = WKA(MsClauseRec, wl);
     const uint32_t nlist = 2 * sh.n_vars;
     const uint32_t ncl = sh.n_orig + w.n_learnts;
@@ -1087,11 +971,11 @@ DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
     w.pool_top = run;
     wave_fence();
     for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
-        const int2 ww = make_int2(wl[c].w0, wl[c].w1);
-        uint32_t pa = atomicAdd(&whdr[ww.x ^ 1].size, 1u);
-        pool[whdr[ww.x ^ 1].base + pa] = make_int2((int)c, ww.y);
-        uint32_t pb = atomicAdd(&whdr[ww.y ^ 1].size, 1u);
-        pool[whdr[ww.y ^ 1].base + pb] = make_int2((int)c, ww.x);
+        const MsClauseRec cr = wl[c];
+        uint32_t pa = atomicAdd(&whdr[cr.w0 ^ 1].size, 1u);
+        pool[whdr[cr.w0 ^ 1].base + pa] = make_int4((int)c, cr.w1, (int)cr.start, (int)cr.size);
+        uint32_t pb = atomicAdd(&whdr[cr.w1 ^ 1].size, 1u);
+        pool[whdr[cr.w1 ^ 1].base + pb] = make_int4((int)c, cr.w0, (int)cr.start, (int)cr.size);
     }
     wave_fence();
 }
@@ -1231,8 +1115,8 @@ DEV int add_learnt(Wk& w, const MsShared& sh, const MsLayout& L, int n, uint32_t
     w.n_learnts++;
     w.lc_lits_n += ((uint32_t)n + 3u) & ~3u;   // next clause starts 16-byte aligned
     wave_fence();
-    if (!list_push_uniform(w, sh, L, l0 ^ 1, cref, l1)) return -1;
-    if (!list_push_uniform(w, sh, L, l1 ^ 1, cref, l0)) return -1;
+    if (!list_push_uniform(w, sh, L, l0 ^ 1, cref, l1, o, (uint32_t)n)) return -1;
+    if (!list_push_uniform(w, sh, L, l1 ^ 1, cref, l0, o, (uint32_t)n)) return -1;
     return cref;
 }
 
@@ -1377,7 +1261,7 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     if (ls.conflicts > 10000 && ls.lbdq_n == MS_LBDQ && (double)w.trail_n > 1.4 * ls.trail_avg) {
         ls.lbdq_n = 0; ls.lbdq_i = 0; ls.lbdq_sum = 0;
     }
-    Learnt lr = analyze(w, sh, L, (uint32_t)(ls.conflicts & 0x3fffu));
+    Learnt lr = analyze<LV>(w, sh, L, (uint32_t)(ls.conflicts & 0x3fffu));
     PROF_MARK(PF_ANALYZE);
     if (w.status != MS_ST_RUNNING) return false;
     const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
@@ -1502,7 +1386,9 @@ __global__ __launch_bounds__(MS_WAVE, ONE ? 1 : MS_SEARCH_WAVES_PER_SIMD) void m
     Wk w;
     w.lane = (int)threadIdx.x;
     w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
+    w.lseen = s_lval + ((sh.n_vars + 15) >> 4);   // (LV) analysis marks behind the assignment words
     if (w.lane == 0) s_ov = 0;
+    if (LV) for (uint32_t i = (uint32_t)w.lane; i < ((sh.n_vars + 31) >> 5); i += MS_WAVE) w.lseen[i] = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     wk_uniformize(w);
     MsState* st = WKA(MsState, state);
@@ -1618,6 +1504,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     Wk w;
     w.lane = (int)threadIdx.x;
     w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
+    w.lseen = s_lval;   // (no analysis in this kernel)
     if (w.lane == 0) s_ov = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     wk_uniformize(w);

@@ -109,7 +109,7 @@ struct MsLayout {
     uint64_t wl;          // MsClauseRec [n_orig + learnt_cap]  watched pair + literal range per clause
     uint64_t whdr;        // MsWatchHdr [2*n_vars]  the literal's watch list (slot in pool, size, capacity) + where its
                           //        binary / ternary lists are in the shared CSRs
-    uint64_t pool;        // int2   [pool_cap]  watcher = (cref, blocker); cref < 0 = tombstone
+    uint64_t pool;        // int4   [pool_cap]  watcher = (cref, blocker, start, size of the clause's literals); cref < 0 = tombstone
     uint64_t lc_lbd;      // uint32 [learnt_cap]  lbd | used<<31
     uint64_t lc_lits;     // int32  [learnt_lit_cap]  (each clause 16-byte aligned)
     uint64_t learnt_buf;  // int32  [n_vars+1]   clause under construction

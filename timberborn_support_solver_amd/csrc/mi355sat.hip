@@ -575,7 +575,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     place(L.exp, 4 * (size_t)MS_EXPORT_RECS * MS_SHARE_REC);
     // the big, cold-tailed arrays last
     place(L.lc_lits, 4 * (size_t)L.learnt_lit_cap);
-    place(L.pool, 8 * (size_t)L.pool_cap);
+    place(L.pool, 16 * (size_t)L.pool_cap);
     L.slab_bytes = align_up(off, 4096);
 
     // Only the head of the slab (everything before lc_lits) plus the initial watch
@@ -608,14 +608,14 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     }
     MsClauseRec* wl = (MsClauseRec*)(T + L.wl);
     MsWatchHdr* whdr = (MsWatchHdr*)(T + L.whdr);
-    int2* pool = (int2*)(T + L.pool);
+    int4* pool = (int4*)(T + L.pool);
     for (size_t t = 0; t < cap.size(); t++)
         whdr[t] = MsWatchHdr{base[t], 0, cap[t], 0, P.lit_hdr[t].bin_off, P.lit_hdr[t].bin_n, P.lit_hdr[t].tern_off, P.lit_hdr[t].tern_n};
     for (uint32_t c = 0; c < no; c++) {
         int32_t a = P.cl_lits[P.cl_hdr[c].start], b = P.cl_lits[P.cl_hdr[c].start + 1];
         wl[c] = MsClauseRec{a, b, P.cl_hdr[c].start, P.cl_hdr[c].size};
-        pool[whdr[a ^ 1].base + whdr[a ^ 1].size++] = make_int2((int)c, b);
-        pool[whdr[b ^ 1].base + whdr[b ^ 1].size++] = make_int2((int)c, a);
+        pool[whdr[a ^ 1].base + whdr[a ^ 1].size++] = make_int4((int)c, b, (int)P.cl_hdr[c].start, (int)P.cl_hdr[c].size);
+        pool[whdr[b ^ 1].base + whdr[b ^ 1].size++] = make_int4((int)c, a, (int)P.cl_hdr[c].start, (int)P.cl_hdr[c].size);
     }
 }
 
@@ -640,7 +640,7 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.sh.tern_owner = s.d_tern_owner.p;
     // assignment in LDS (2 bits per variable) when it still leaves room for 12 waves per CU
     // (measured on rect 64x64: 12 waves/CU with the assignment in HBM beat 6 waves/CU with it in LDS)
-    s.lds_val_bytes = ((P.n_vars + 15) / 16) * 4;
+    s.lds_val_bytes = ((P.n_vars + 15) / 16) * 4 + ((P.n_vars + 31) / 32) * 4;   // 2-bit assignment + 1-bit analysis marks
     s.lds_val = s.opts.lds_val == 1 || (s.opts.lds_val == 0 && s.lds_val_bytes <= 10 * 1024);
     if (s.lds_val_bytes > 150 * 1024) s.lds_val = false;
     // worker count limited by free HBM
@@ -689,7 +689,7 @@ void replicate_template(mi355sat& s, uint32_t from, uint32_t to) {   // workers 
     if (to <= from) return;
     hipLaunchKernelGGL(ms_replicate_kernel, dim3(64, to - from), dim3(256), 0, s.stream, (const char*)s.d_template.p,
                        s.d_slabs.p + (size_t)from * L.slab_bytes, (uint64_t)L.slab_bytes, (uint64_t)head, (uint64_t)L.pool,
-                       (uint64_t)(8 * s.pool_init));
+                       (uint64_t)(16 * s.pool_init));
     HIPCHK(hipGetLastError());
 }
 
@@ -822,15 +822,24 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
         prm.share_pool = s.d_share_pool.p;
         prm.share_n = s.d_share_n.p;
         prm.share_slots = s.share_slots;
-        prm.share_max_lbd = s.opts.share_lbd > 0 ? (uint32_t)s.opts.share_lbd : 2u;
+        prm.share_max_lbd = s.opts.share_lbd > 0 ? (uint32_t)s.opts.share_lbd : 4u;
         prm.share_max_len = s.opts.share_len > 0 ? (uint32_t)s.opts.share_len : (uint32_t)MS_SHARE_MAXLEN;
         prm.share_interval = s.opts.share_interval > 0 ? (uint32_t)s.opts.share_interval : 0xffffffffu;
     }
-    const uint32_t dyn = s.lds_val ? s.lds_val_bytes : 0;
+    // Assignment (2 bits / variable) and analysis marks (1 bit) in LDS when this launch's workers per CU leave room
+    // (160 KB per CU; a workgroup's static 3 KB aside): 16 workers per CU -> 9 KB each (the round-1 rule), one per CU
+    // -> up to 64 KB, which covers rect 64x64.  State is written back to HBM at every slice end, so consecutive
+    // launches may differ.
+    bool lds = s.lds_val;
+    if (mode == 0 && s.opts.lds_val == 0) {
+        const uint32_t per_cu = (active + 255) / 256;
+        lds = s.lds_val_bytes <= std::min<uint32_t>(64 * 1024, 150 * 1024 / per_cu - 3 * 1024);
+    }
+    const uint32_t dyn = lds ? s.lds_val_bytes : 0;
     HIPCHK(hipEventRecord(s.ev0, s.stream));
     if (mode == 0) {
         const bool one = s.opts.one_per_simd >= 0 && active <= 1024;   // at most one worker per SIMD: the no-spill build
-        if (s.lds_val) {
+        if (lds) {
             if (one) hipLaunchKernelGGL((ms_search_kernel<true, true>), dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
             else hipLaunchKernelGGL((ms_search_kernel<true, false>), dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
         } else {
@@ -838,7 +847,7 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
             else hipLaunchKernelGGL((ms_search_kernel<false, false>), dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
         }
     } else {
-        if (s.lds_val) hipLaunchKernelGGL(ms_bcp_kernel<true>, dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        if (lds) hipLaunchKernelGGL(ms_bcp_kernel<true>, dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
         else hipLaunchKernelGGL(ms_bcp_kernel<false>, dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
     }
     HIPCHK(hipGetLastError());
