@@ -90,6 +90,10 @@ typedef struct mi355sat_opts {
     int32_t one_per_simd;      /* 0 = default: a launch of at most 1024 workers (one per SIMD) runs the build of the search
                                   kernel that owns the SIMD's whole register file (no spills, everything inlined);
                                   -1 = always the 4-waves-per-SIMD build (A/B) */
+    int32_t simp;              /* formula simplification before search (the reference's backend is `simp::Glucose`): 0 = default
+                                  (on): equivalent-literal substitution, failed-literal probing on the device, subsumption and
+                                  self-subsuming resolution on the device; -1 = only level-0 unit propagation.  Invisible at this
+                                  interface: models, assumptions and proofs stay in the caller's variables. */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
 } mi355sat_opts;
@@ -118,7 +122,9 @@ typedef struct mi355sat_stats_t {
     uint64_t shared_exported;  /* clauses workers offered to the exchange / clauses (and units) attached from it, */
     uint64_t shared_imported;  /* summed over workers */
     uint64_t shared_imported_units;
-    uint64_t reserved[3];
+    uint64_t simp_units;           /* simplification before search: failed literals + necessary assignments found by probing */
+    uint64_t simp_equivalences;    /* variables replaced by an equivalent literal */
+    uint64_t simp_clauses_removed; /* clauses subsumed or strengthened */
 } mi355sat_stats_t;
 
 /* --- lifecycle (Default::default / Drop) --------------------------------- */

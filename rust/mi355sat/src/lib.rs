@@ -21,7 +21,7 @@ pub struct Opts {
     pub device: i32, pub workers: i32, pub conflict_budget: i64, pub slice_conflicts: i32, pub seed: u64,
     pub verbose: i32, pub reduce_first: i32, pub reduce_inc: i32, pub lds_val: i32, pub max_groups: i32,
     pub slice_ms: i32, pub cube_split: i32, pub share: i32, pub share_lbd: i32, pub share_len: i32,
-    pub share_interval: i32, pub var_order: i32, pub ramp: i32, pub one_per_simd: i32, pub rebalance: i32,
+    pub share_interval: i32, pub var_order: i32, pub ramp: i32, pub one_per_simd: i32, pub simp: i32, pub rebalance: i32,
 }
 
 /// Mirror of `mi355sat_stats_t`.
@@ -33,7 +33,7 @@ pub struct Stats {
     pub solve_seconds: f64, pub kernel_seconds: f64, pub kernel_launches: u64, pub n_deq: u64, pub n_watch: u64,
     pub n_cl_lit: u64, pub n_move: u64, pub n_enq: u64, pub n_sat: u64, pub n_unsat: u64, pub n_terminated: u64,
     pub bcp_steps: u64, pub bcp_requeued: u64, pub shared_exported: u64, pub shared_imported: u64,
-    pub shared_imported_units: u64, reserved: [u64; 3],
+    pub shared_imported_units: u64, pub simp_units: u64, pub simp_equivalences: u64, pub simp_clauses_removed: u64,
 }
 
 extern "C" {

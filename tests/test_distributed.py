@@ -64,7 +64,7 @@ def _sharded_worker(rank, world, port, q, terrain, pset, k0):
     lines, st = [], {}
     # real solves: the product's kernels in the wavefront-emulator build, a few workers per rank
     hist = solver_loop_sweep_sharded(grid, enc, PlatformLimits({(1, 1): k0}), out=lines.append, time_limit=600,
-                                     make_solver=lambda: Mi355Sat(_lib_override=emu_lib(), workers=6, slice_conflicts=30,
+                                     make_solver=lambda: Mi355Sat(_lib_override=emu_lib(), workers=6, slice_conflicts=30, simp=-1,
                                                                   seed=100 + rank),
                                      stats_out=st)
     best = [h for h in hist if h["result"].name == "Sat"][-1]

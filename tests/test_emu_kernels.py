@@ -17,6 +17,7 @@ SMALL = [v for v in VERDICTS["verdicts"] if v["n_clauses"] < 1300 or (v["terrain
 
 
 def emu_solver(**kw):
+    kw.setdefault("simp", -1)      # probing through the fiber emulator is slow: the simplification has its own tests below
     return Mi355Sat(_lib_override=emu_lib(), **kw)
 
 
@@ -333,4 +334,82 @@ def test_emulated_assignment_in_hbm_variant(tmp_path):
         assert c == confl[i]
         if not c:
             assert np.array_equal(v, vals[i]) and n == tl[i]
+    s.close()
+
+
+@pytest.mark.parametrize("terrain,pset,k,want", [("ex1", "1x1", 2, "Unsat"), ("ex1", "1x1", 3, "Sat"), ("ex1", "default", 1, "Sat"),
+                                                  ("ex3", "1x1", 4, "Sat")])
+def test_emulated_simplification_keeps_verdicts_models_and_proofs(tmp_path, terrain, pset, k, want):
+    """SURVEY 8 f3 (`simp::Glucose`, crates/repl/src/main.rs:17): equivalent-literal substitution, failed-literal
+    probing (ms_probe_kernel) and subsumption (ms_subsume_kernel) before the search.  Verdicts are those without
+    it; models come back in the caller's variables and satisfy the ORIGINAL clauses; the DRUP proof (simplification
+    lemmas first, then the search's) passes the oracle's RUP checker against the original formula."""
+    from timberborn_support_solver_amd.dimacs import read_drup
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+    proof = str(tmp_path / "p.drup")
+    s = emu_solver(workers=2, simp=0)
+    if want == "Unsat":
+        s.set_proof_path(proof)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    r = s.solve()
+    assert r.name == want
+    st = s.stats()
+    assert st["simp_units"] > 0                               # probing found failed literals on every one of these
+    if r == SolverResult.Sat:
+        check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+    else:
+        assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof)) == 1
+    s.close()
+
+
+def test_emulated_simplification_substitutes_equivalent_literals_and_maps_models_back():
+    """A chain of equivalences (x1 = x2 = ~x3 as binary implication cycles) plus clauses over them: the substituted
+    variables must come back with their representative's value, assumptions on substituted variables must work,
+    and a formula that forces x and ~x into one component is UNSAT without search."""
+    cl = [[-1, 2], [-2, 1], [-2, -3], [3, 2], [1, 3, 4, 5], [-4, -5, 6, 7], [-1, 4, 6, 7], [-6, -7, 8, 9]]
+    s = emu_solver(workers=1, simp=0)
+    for c in cl:
+        s.add_clause(c)
+    assert s.solve() == SolverResult.Sat
+    m = s.full_solution(9)
+    assert ora.check_model(*ora.to_csr(cl), m) == -1 and m[0] == m[1] == -m[2]
+    assert s.stats()["simp_equivalences"] >= 2
+    s.close()
+    s = emu_solver(workers=2, simp=0)
+    for c in cl:
+        s.add_clause(c)
+    res = s.solve_batch([[3], [-2, 3], [2, -4, -5]])            # x3 forces ~x1, ~x2;  ~x2 & x3 consistent;  x2 -> x1 -> needs 4..7
+    assert [r.name for r in res] == ["Sat", "Sat", "Sat"]
+    for i, a in enumerate([[3], [-2, 3], [2, -4, -5]]):
+        m = s.solution_of(i, 9)
+        assert ora.check_model(*ora.to_csr(cl + [[l] for l in a]), m) == -1
+    s.close()
+    s = emu_solver(workers=1, simp=0)
+    for c in cl + [[1, 3, 9], [-9, 1], [-1, -3, 9], [2, -9, 3], [-2, 3]]:   # x2 -> x3 closes the cycle x2 -> x3 -> ~x2
+        s.add_clause(c)
+    o = ora.OracleSolver()
+    lits, offs = ora.to_csr(cl + [[1, 3, 9], [-9, 1], [-1, -3, 9], [2, -9, 3], [-2, 3]])
+    o.add_cnf(lits, offs)
+    assert s.solve().value == o.solve()
+    s.close()
+
+
+def test_emulated_subsumption_kernel_removes_and_strengthens():
+    """(a | b) subsumes (a | b | c); (a | ~c) strengthens (a | b | c | d) ... to (a | b | d) only via (a|~c)+(a|b|c|d):
+    checked through the counters and by equivalence of the answers under every assumption of the inputs."""
+    import itertools
+    cl = [[1, 2], [1, 2, 3], [1, 2, 3, 4], [1, -3], [-1, 5, 6], [-1, 5, 6, 7], [2, 3, 4, 5], [-2, 3, 4, 5], [5, 6, 7, 8]]
+    s = emu_solver(workers=2, simp=0)
+    for c in cl:
+        s.add_clause(c)
+    sets = [[v if b else -v for v, b in zip(range(1, 5), bits)] for bits in itertools.product([0, 1], repeat=4)]
+    res = s.solve_batch(sets)
+    assert s.stats()["simp_clauses_removed"] >= 3
+    for a, r in zip(sets, res):
+        o = ora.OracleSolver()
+        lits, offs = ora.to_csr(cl)
+        o.add_cnf(lits, offs)
+        assert r.value == o.solve(a), a
     s.close()

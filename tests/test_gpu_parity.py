@@ -446,3 +446,25 @@ def test_rectangular_type_limit_on_the_gpu():
                     assert sum(c for (w, h), c in stats.items() if w >= d[0] and h >= d[1]) <= n, (lim, stats)
         s.close()
     assert seen == {10, 20}
+
+
+@pytest.mark.parametrize("terrain,pset,k,want", [("rect16x16", "default", 3, "Unsat"), ("rect16x16", "default", 4, "Sat"),
+                                                  ("ex2", "1x1", 14, "Sat"), ("ex3", "default", 1, "Sat"),
+                                                  ("rect24x24", "default", 8, "Unsat"), ("rect24x24", "default", 9, "Sat")])
+def test_simplification_before_search_keeps_verdicts_and_models(terrain, pset, k, want):
+    """SURVEY 8 f3 (`simp::Glucose`, crates/repl/src/main.rs:17): with the device-side simplification on (the
+    default: equivalent literals, failed-literal probing, subsumption) and off, the verdict is the golden one;
+    models are in the caller's variables and satisfy the ORIGINAL clauses; the counters show it ran."""
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+    for simp in (0, -1):
+        s = Mi355Sat(simp=simp)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        r = solve_within(s, HARD_RUNG_LIMIT_S)
+        assert r.name == want, (terrain, pset, k, simp)
+        st = s.stats()
+        assert (st["simp_units"] + st["simp_equivalences"] + st["simp_clauses_removed"] > 0) == (simp == 0)
+        if r == SolverResult.Sat:
+            check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+        s.close()

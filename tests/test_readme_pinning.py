@@ -44,7 +44,7 @@ def test_printed_layouts_are_models_of_product_and_oracle_cnf(lay):
             lay_out = check_sat_answer(cnf, s.model(cnf.n_vars), enc, grid, kk)
             assert sorted((x, y) for x, y, *_ in lay_out.platforms()) == sorted(tuple(p) for p in lay["supports_xy"])
         # the kernel logic (wavefront emulator build of the product library) on the product CNF
-        e = Mi355Sat(_lib_override=emu_lib(), workers=2)
+        e = Mi355Sat(_lib_override=emu_lib(), workers=2, simp=-1)
         e.add_cnf(cnf.lits, cnf.offsets)
         assert e.solve_batch([a])[0].value == want
         e.close()

@@ -1525,3 +1525,91 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     if (w.status == MS_ST_RUNNING) w.status = confl ? MS_ST_UNSAT : MS_ST_SAT;
     wk_store<LV>(w, sh, L, __builtin_readcyclecounter() - t0);
 }
+
+// ---- failed-literal probing (formula simplification before search) -----------------------------------
+// The reference's backend is `simp::Glucose` (crates/repl/src/main.rs:17): it simplifies the formula before it
+// searches.  Probing is the part of that which is unit propagation, i.e. this kernel's hot loop: worker w takes the
+// probe literals of its script one after the other - assume the literal at decision level 1, propagate to fixpoint,
+// note the outcome, backtrack - and both polarities of a variable go to the same worker back to back, so that it can
+// compare what they imply:
+//   p -> conflict                      : ~p is a consequence of the formula (failed literal)
+//   p -> m  and  ~p -> m               : m is a consequence (necessary assignment)
+//   p -> m  and  ~p -> ~m              : m == p (equivalent literals)
+// Results: script[d] is overwritten with the number of literals the probe implied, or -1 for a failed literal, or -2
+// if it was not probed (already assigned); facts go to `toclear` as (kind, a, b) triples: kind 1 = unit a,
+// kind 2 = a == b; their number to learnt_buf[0].
+template <bool LV>
+__global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
+    __shared__ int32_t s_ring[MS_LDS_RING];
+    __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
+    __shared__ uint32_t s_hist[64];
+    __shared__ int32_t s_bfl[MS_MAX_GROUPS];
+    __shared__ uint32_t s_ov;
+    HIP_DYNAMIC_SHARED(uint32_t, s_lval)
+    const uint32_t wid = blockIdx.x;
+    if (wid >= prm.n_workers) return;
+    Wk w;
+    w.lane = (int)threadIdx.x;
+    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
+    w.lseen = s_lval;
+    if (w.lane == 0) s_ov = 0;
+    wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
+    wk_uniformize(w);
+    lds_fence();
+    const u64 t0 = __builtin_readcyclecounter();
+    const int n_script = WKA(MsState, state)->n_script;
+    int32_t* script = WK_PTR(int32_t, w, L, script);
+    uint32_t* stamp = WK_PTR(uint32_t, w, L, lvl_stamp);     // per variable: (probe index + 1) << 1 | sign of the implied literal
+    int32_t* facts = WK_PTR(int32_t, w, L, toclear);
+    const int fact_cap = ((int)sh.n_vars + 1) / 3;
+    int n_facts = 0;
+    bool confl = propagate<LV>(w, sh, L);      // the formula's own units (normally already at their fixpoint)
+    int prev_a = -1;                           // literal of the previous probe if it ran to a fixpoint, else -1
+    for (int d = 0; d < n_script && !confl && w.status == MS_ST_RUNNING; d++) {
+        const int a = uni(script[d]);
+        int res = -2;
+        bool ran = false;
+        if (lit_value<LV>(w, sh, L, a) == MS_VAL_UNDEF) {
+            const int base = w.trail_n;
+            new_decision_level(w, sh, L);
+            enqueue_uniform<LV>(w, sh, L, a, MS_REASON_NONE);
+            const bool failed = propagate<LV>(w, sh, L);
+            res = failed ? -1 : w.trail_n - base - 1;
+            // the partner probe (same variable, other polarity) is the previous script entry
+            const bool second = prev_a == (a ^ 1);
+            ran = !failed;
+            if (!failed) {
+                const int32_t* trail = WKA(int32_t, trail);
+                const uint32_t mine = (uint32_t)(d + 1) << 1, prev = (uint32_t)d << 1;
+                for (int i0 = base + 1; i0 < w.trail_n; i0 += MS_WAVE) {
+                    const int i = i0 + w.lane;
+                    const bool in = i < w.trail_n;
+                    const int m = in ? trail[i] : 0;
+                    int kind = 0;
+                    if (in) {
+                        const uint32_t st = stamp[m >> 1];
+                        if (second && (st >> 1) == (prev >> 1)) kind = (st & 1u) == (uint32_t)(m & 1) ? 1 : 2;
+                        stamp[m >> 1] = mine | (uint32_t)(m & 1);
+                    }
+                    const u64 km = ballot(kind != 0);
+                    if (kind != 0) {
+                        const int o = n_facts + popc64(km & lanemask_lt(w.lane));
+                        // kind 2: the previous probe (~a) implied ~m and this one (a) implies m: m == a
+                        if (o < fact_cap) { facts[3 * o] = kind; facts[3 * o + 1] = m; facts[3 * o + 2] = a; }
+                    }
+                    n_facts += popc64(km);
+                    wave_fence();
+                }
+            }
+            cancel_until<LV>(w, sh, L, 0);
+            w.confl_kind = 0;
+        }
+        prev_a = ran ? a : -1;
+        wave_fence();
+        if (w.lane == 0) script[d] = res;
+        wave_fence();
+    }
+    if (w.lane == 0) WK_PTR(int32_t, w, L, learnt_buf)[0] = n_facts < fact_cap ? n_facts : fact_cap;
+    if (w.status == MS_ST_RUNNING) w.status = confl ? MS_ST_UNSAT : MS_ST_SAT;
+    wk_store<LV>(w, sh, L, __builtin_readcyclecounter() - t0);
+}

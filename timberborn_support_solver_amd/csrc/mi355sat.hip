@@ -178,6 +178,57 @@ __global__ void ms_share_collect_kernel(MsLayout L, char* slabs, uint32_t n_work
     st->exp_n = 0;
 }
 
+// Subsumption and self-subsuming resolution (the other half of what `simp::Glucose` does before search; its
+// variable elimination is not restated: measured to remove < 15 % of these encodings' variables).  One thread per
+// clause C (literals sorted): every clause D in the occurrence list of C's rarest literal p is merged against C -
+// C inside D: D is subsumed;  C inside D except ONE literal x that D has negated: D loses ~x (the resolvent of C and
+// D on x subsumes D).  The list of ~p finds the D's that lose ~p.  sig = 64-bit signature over VARIABLES
+// (sig(C) & ~sig(D) != 0 rules D out without touching its literals).
+__device__ inline int subsume_check(const int32_t* lits, const uint64_t* offs, uint32_t c, uint32_t d) {
+    // 0 no, 1 C subsumes D, 2 + x: D can drop literal ~x  (returned as 2 + (~x))
+    uint64_t i = offs[c], ie = offs[c + 1], j = offs[d], je = offs[d + 1];
+    int flip = -1;
+    for (; i < ie; i++) {
+        const int32_t a = lits[i];
+        while (j < je && (lits[j] >> 1) < (a >> 1)) j++;
+        if (j == je || (lits[j] >> 1) != (a >> 1)) return 0;
+        if (lits[j] != a) {
+            if (flip >= 0) return 0;
+            flip = lits[j];
+        }
+        j++;
+    }
+    return flip < 0 ? 1 : 2 + flip;
+}
+__global__ void ms_subsume_kernel(uint32_t n_clauses, const int32_t* lits, const uint64_t* offs, const unsigned long long* sig,
+                                  const uint32_t* occ_off, const uint32_t* occ, uint32_t max_size, uint32_t* subsumed,
+                                  int32_t* drop_lit) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clauses) return;
+    const uint32_t sz = (uint32_t)(offs[c + 1] - offs[c]);
+    if (sz > max_size) return;
+    int32_t p = lits[offs[c]];
+    uint32_t best = 0xffffffffu;
+    for (uint64_t k = offs[c]; k < offs[c + 1]; k++) {
+        const int32_t l = lits[k];
+        const uint32_t n = (occ_off[l + 1] - occ_off[l]) + (occ_off[(l ^ 1) + 1] - occ_off[l ^ 1]);
+        if (n < best) { best = n; p = l; }
+    }
+    const unsigned long long sc = sig[c];
+    for (int side = 0; side < 2; side++) {
+        const int32_t q = side ? (p ^ 1) : p;
+        for (uint32_t e = occ_off[q]; e < occ_off[q + 1]; e++) {
+            const uint32_t d = occ[e];
+            if (d == c || (sc & ~sig[d]) != 0) continue;
+            const uint32_t dz = (uint32_t)(offs[d + 1] - offs[d]);
+            if (dz < sz) continue;
+            const int r = subsume_check(lits, offs, c, d);
+            if (r == 1) { if (dz > sz || c < d) subsumed[d] = 1; }          // equal clauses: the lower index stays
+            else if (r >= 2) atomicCAS((int*)&drop_lit[d], -1, r - 2);      // one literal per clause and pass
+        }
+    }
+}
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -301,6 +352,8 @@ struct mi355sat {
     std::vector<int8_t> fixed;                 // per var: 0 free, 1 true, -1 false (level-0 facts)
     uint32_t n_vars = 0;
     std::vector<uint32_t> perm;                // caller's variable index -> device variable index (Prepared::perm)
+    std::vector<int32_t> subst;                // per caller variable: the literal (2*var + neg) that replaced it, or itself
+    std::vector<int32_t> simp_proof;           // DRUP lemmas of the simplification (internal literals, -1 terminated)
     struct SweepHolder* sweep = nullptr;        // stepwise sweep in progress (mi355sat_sweep_*)
 };
 
@@ -389,87 +442,121 @@ void locality_order(uint32_t nv, const std::vector<int32_t>& nl, const std::vect
     for (uint32_t v = 0; v < nv; v++) if (perm[v] == NONE) perm[v] = next++;
 }
 
-void prepare(const mi355sat& s, bool simplify, Prepared& P) {
-    const uint32_t nv = (uint32_t)s.max_var;
-    P.n_vars = nv;
-    const size_t nc = s.offs.size() - 1;
-    std::vector<int8_t> val(nv, 0);  // 0 unassigned, 1 true, -1 false
-    // normalised clauses
-    std::vector<int32_t> nl;
-    std::vector<uint64_t> no{0};
-    nl.reserve(s.lits.size());
-    std::vector<int32_t> tmp;
-    auto assign_unit = [&](int32_t l) -> bool {  // false on contradiction
-        int8_t want = (l & 1) ? -1 : 1;
+// The caller's clauses in normal form (internal literals 2*var + neg, caller's numbering; sorted, no duplicate
+// literals, no tautologies, no units): what the simplification steps work on.
+struct Formula {
+    uint32_t nv = 0;
+    bool unsat = false;
+    std::vector<int32_t> nl;                 // literals
+    std::vector<uint64_t> no{0};             // clause offsets
+    std::vector<int8_t> val;                 // level-0 facts: 0 unassigned, 1 true, -1 false
+    std::vector<int32_t> units;              // the same as a list, in derivation order
+    size_t units_done = 0;                   // units[0..units_done) have been propagated through nl / no
+    std::vector<int32_t> subst;              // per variable: the literal that replaces it (2*v = itself)
+    std::vector<int32_t> proof;              // DRUP lemmas justifying units / equivalences / rewritten clauses (-1 terminated)
+    bool log_proof = false;
+    uint64_t n_failed = 0, n_necessary = 0, n_equiv = 0, n_subsumed = 0, n_strengthened = 0;
+    size_t n_clauses() const { return no.size() - 1; }
+    int8_t lv(int32_t l) const { int8_t v = val[l >> 1]; return (l & 1) ? (int8_t)-v : v; }
+    bool assign_unit(int32_t l) {            // false on contradiction
+        const int8_t want = (l & 1) ? -1 : 1;
         int8_t& v = val[l >> 1];
-        if (v == 0) { v = want; P.units.push_back(l); return true; }
+        if (v == 0) { v = want; units.push_back(l); return true; }
         return v == want;
-    };
-    for (size_t c = 0; c < nc && !P.unsat; c++) {
+    }
+    void lemma(std::initializer_list<int32_t> c) { if (log_proof) { proof.insert(proof.end(), c); proof.push_back(-1); } }
+    void lemma(const std::vector<int32_t>& c) { if (log_proof) { proof.insert(proof.end(), c.begin(), c.end()); proof.push_back(-1); } }
+};
+
+// Sort / dedupe / drop tautologies of one clause; units go to F.val.  Returns false if the clause is dropped.
+bool normal_clause(Formula& F, std::vector<int32_t>& tmp) {
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    for (size_t i = 0; i + 1 < tmp.size(); i++) if ((tmp[i] ^ 1) == tmp[i + 1]) return false;
+    if (tmp.empty()) { F.unsat = true; return false; }
+    if (tmp.size() == 1) { if (!F.assign_unit(tmp[0])) F.unsat = true; return false; }
+    return true;
+}
+
+void normalise(const mi355sat& s, Formula& F) {
+    F.nv = (uint32_t)s.max_var;
+    F.val.assign(F.nv, 0);
+    F.subst.resize(F.nv);
+    for (uint32_t v = 0; v < F.nv; v++) F.subst[v] = 2 * (int32_t)v;
+    const size_t nc = s.offs.size() - 1;
+    F.nl.reserve(s.lits.size());
+    std::vector<int32_t> tmp;
+    for (size_t c = 0; c < nc && !F.unsat; c++) {
         tmp.clear();
         for (uint64_t k = s.offs[c]; k < s.offs[c + 1]; k++) tmp.push_back(to_internal(s.lits[k]));
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        bool taut = false;
-        for (size_t i = 0; i + 1 < tmp.size(); i++) taut = taut || (tmp[i] ^ 1) == tmp[i + 1];
-        if (taut) continue;
-        if (tmp.empty()) { P.unsat = true; break; }
-        if (tmp.size() == 1) { if (!assign_unit(tmp[0])) P.unsat = true; continue; }
-        nl.insert(nl.end(), tmp.begin(), tmp.end());
-        no.push_back(nl.size());
+        if (!normal_clause(F, tmp)) continue;
+        F.nl.insert(F.nl.end(), tmp.begin(), tmp.end());
+        F.no.push_back(F.nl.size());
     }
-    if (P.unsat) return;
-    size_t nn = no.size() - 1;
-    if (simplify) {
-        // level-0 unit propagation over occurrence lists, then strip
-        std::vector<uint32_t> occ_off(2 * (size_t)nv + 1, 0);
-        for (int32_t l : nl) occ_off[l + 1]++;
-        for (size_t i = 0; i < 2 * (size_t)nv; i++) occ_off[i + 1] += occ_off[i];
-        std::vector<uint32_t> occ(nl.size()), fill(occ_off.begin(), occ_off.end() - 1);
-        for (size_t c = 0; c < nn; c++)
-            for (uint64_t k = no[c]; k < no[c + 1]; k++) occ[fill[nl[k]]++] = (uint32_t)c;
-        auto lv = [&](int32_t l) { int8_t v = val[l >> 1]; return (l & 1) ? (int8_t)-v : v; };
-        size_t qh = 0;
-        while (qh < P.units.size() && !P.unsat) {
-            int32_t p = P.units[qh++];
-            int32_t f = p ^ 1;
-            for (uint32_t e = occ_off[f]; e < occ_off[f + 1] && !P.unsat; e++) {
-                uint32_t c = occ[e];
-                int32_t unit = -1;
-                int nfree = 0;
-                bool sat = false;
-                for (uint64_t k = no[c]; k < no[c + 1]; k++) {
-                    int8_t v = lv(nl[k]);
-                    if (v > 0) { sat = true; break; }
-                    if (v == 0) { nfree++; unit = nl[k]; }
-                }
-                if (sat) continue;
-                if (nfree == 0) P.unsat = true;
-                else if (nfree == 1 && !assign_unit(unit)) P.unsat = true;
-            }
-        }
-        if (P.unsat) return;
-        P.units_propagated = true;
-        std::vector<int32_t> nl2;
-        std::vector<uint64_t> no2{0};
-        nl2.reserve(nl.size());
-        for (size_t c = 0; c < nn; c++) {
+}
+
+// Level-0 unit propagation over occurrence lists, then strip satisfied clauses and false literals.
+void propagate_units(Formula& F) {
+    if (F.unsat || F.units_done == F.units.size()) return;
+    const uint32_t nv = F.nv;
+    const size_t nn = F.n_clauses();
+    std::vector<uint32_t> occ_off(2 * (size_t)nv + 1, 0);
+    for (int32_t l : F.nl) occ_off[l + 1]++;
+    for (size_t i = 0; i < 2 * (size_t)nv; i++) occ_off[i + 1] += occ_off[i];
+    std::vector<uint32_t> occ(F.nl.size()), fill(occ_off.begin(), occ_off.end() - 1);
+    for (size_t c = 0; c < nn; c++)
+        for (uint64_t k = F.no[c]; k < F.no[c + 1]; k++) occ[fill[F.nl[k]]++] = (uint32_t)c;
+    size_t qh = F.units_done;
+    while (qh < F.units.size() && !F.unsat) {
+        const int32_t f = F.units[qh++] ^ 1;
+        for (uint32_t e = occ_off[f]; e < occ_off[f + 1] && !F.unsat; e++) {
+            const uint32_t c = occ[e];
+            int32_t unit = -1;
+            int nfree = 0;
             bool sat = false;
-            size_t start = nl2.size();
-            for (uint64_t k = no[c]; k < no[c + 1]; k++) {
-                int8_t v = lv(nl[k]);
+            for (uint64_t k = F.no[c]; k < F.no[c + 1]; k++) {
+                const int8_t v = F.lv(F.nl[k]);
                 if (v > 0) { sat = true; break; }
-                if (v == 0) nl2.push_back(nl[k]);
+                if (v == 0) { nfree++; unit = F.nl[k]; }
             }
-            if (sat) { nl2.resize(start); continue; }
-            no2.push_back(nl2.size());
+            if (sat) continue;
+            if (nfree == 0) F.unsat = true;
+            else if (nfree == 1 && !F.assign_unit(unit)) F.unsat = true;
         }
-        nl.swap(nl2);
-        no.swap(no2);
-        nn = no.size() - 1;
     }
+    if (F.unsat) return;
+    F.units_done = F.units.size();
+    std::vector<int32_t> nl2;
+    std::vector<uint64_t> no2{0};
+    nl2.reserve(F.nl.size());
+    for (size_t c = 0; c < nn; c++) {
+        bool sat = false;
+        const size_t start = nl2.size();
+        for (uint64_t k = F.no[c]; k < F.no[c + 1]; k++) {
+            const int8_t v = F.lv(F.nl[k]);
+            if (v > 0) { sat = true; break; }
+            if (v == 0) nl2.push_back(F.nl[k]);
+        }
+        if (sat) { nl2.resize(start); continue; }
+        no2.push_back(nl2.size());
+    }
+    F.nl.swap(nl2);
+    F.no.swap(no2);
+}
+
+// Device form of the formula: variable order, binary / ternary CSRs, long clauses.
+void build_csr(const mi355sat& s, const Formula& F, bool units_propagated, Prepared& P) {
+    const uint32_t nv = F.nv;
+    P.n_vars = nv;
+    P.unsat = F.unsat;
+    P.units = F.units;
+    P.units_propagated = units_propagated;
+    if (P.unsat) return;
+    std::vector<int32_t> nl = F.nl;
+    const std::vector<uint64_t>& no = F.no;
+    const size_t nn = F.n_clauses();
     // device variable order
-    if (s.opts.var_order > 0) locality_order(nv, nl, no, val, P.perm);
+    if (s.opts.var_order > 0) locality_order(nv, nl, no, F.val, P.perm);
     else { P.perm.resize(nv); for (uint32_t v = 0; v < nv; v++) P.perm[v] = v; }
     for (auto& l : nl) l = 2 * (int32_t)P.perm[l >> 1] | (l & 1);
     for (auto& l : P.units) l = 2 * (int32_t)P.perm[l >> 1] | (l & 1);
@@ -487,8 +574,10 @@ void prepare(const mi355sat& s, bool simplify, Prepared& P) {
         }
     }
     for (int k = 0; k < 4; k++) P.cl_lits.push_back(0);  // a lane may read one 16-byte group past the last clause
+    for (auto& b : bins) if (b.first > b.second) std::swap(b.first, b.second);
     std::sort(bins.begin(), bins.end());
     bins.erase(std::unique(bins.begin(), bins.end()), bins.end());
+    for (auto& c : terns) std::sort(c.begin(), c.end());
     std::sort(terns.begin(), terns.end());
     terns.erase(std::unique(terns.begin(), terns.end()), terns.end());
     P.lit_hdr.assign(2 * (size_t)nv, MsLitHdr{0, 0, 0, 0});
@@ -520,6 +609,13 @@ void prepare(const mi355sat& s, bool simplify, Prepared& P) {
                 P.tern_owner[e] = c[k] ^ 1;
             }
     }
+}
+
+void prepare(const mi355sat& s, bool simplify, Prepared& P) {
+    Formula F;
+    normalise(s, F);
+    if (simplify) propagate_units(F);
+    build_csr(s, F, simplify, P);
 }
 
 // ---- slab template -----------------------------------------------------------------
@@ -755,6 +851,255 @@ void gather_states(mi355sat& s, std::vector<MsState>& out) {
     HIPCHK(hipStreamSynchronize(s.stream));
 }
 
+// ---- formula simplification before search (`simp::Glucose`, crates/repl/src/main.rs:17) --------------------------
+// Equivalent-literal substitution: strongly connected components of the binary implication graph (iterative
+// Tarjan on the host - a few 10^5 edges), every literal replaced by the smallest literal of its component.
+uint64_t els_scc(Formula& F) {
+    if (F.unsat) return 0;
+    const uint32_t nl2 = 2 * F.nv;
+    const size_t nn = F.n_clauses();
+    std::vector<uint32_t> off(nl2 + 1, 0);
+    for (size_t c = 0; c < nn; c++)
+        if (F.no[c + 1] - F.no[c] == 2) { off[(F.nl[F.no[c]] ^ 1) + 1]++; off[(F.nl[F.no[c] + 1] ^ 1) + 1]++; }
+    for (uint32_t i = 0; i < nl2; i++) off[i + 1] += off[i];
+    std::vector<int32_t> adj(off[nl2]);
+    {
+        std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+        for (size_t c = 0; c < nn; c++)
+            if (F.no[c + 1] - F.no[c] == 2) {
+                const int32_t a = F.nl[F.no[c]], b = F.nl[F.no[c] + 1];
+                adj[fill[a ^ 1]++] = b;
+                adj[fill[b ^ 1]++] = a;
+            }
+    }
+    std::vector<int32_t> index(nl2, -1), low(nl2, 0), rep(nl2, -1), stack, work, it(nl2, 0);
+    std::vector<uint8_t> on(nl2, 0);
+    int32_t counter = 0;
+    for (uint32_t root = 0; root < nl2; root++) {
+        if (index[root] >= 0 || off[root] == off[root + 1]) continue;
+        work.push_back((int32_t)root);
+        while (!work.empty()) {
+            const int32_t v = work.back();
+            if (index[v] < 0) { index[v] = low[v] = counter++; stack.push_back(v); on[v] = 1; it[v] = (int32_t)off[v]; }
+            bool descended = false;
+            while (it[v] < (int32_t)off[v + 1]) {
+                const int32_t u = adj[it[v]++];
+                if (index[u] < 0) { work.push_back(u); descended = true; break; }
+                if (on[u]) low[v] = std::min(low[v], index[u]);
+            }
+            if (descended) continue;
+            if (low[v] == index[v]) {
+                size_t k = stack.size();
+                int32_t m = v;
+                do { k--; m = std::min(m, stack[k]); } while (stack[k] != v);
+                for (size_t j = k; j < stack.size(); j++) { rep[stack[j]] = m; on[stack[j]] = 0; }
+                stack.resize(k);
+            }
+            work.pop_back();
+            if (!work.empty()) low[work.back()] = std::min(low[work.back()], low[v]);
+        }
+    }
+    uint64_t n_sub = 0;
+    std::vector<int32_t> map(nl2);
+    for (uint32_t l = 0; l < nl2; l++) map[l] = (int32_t)l;
+    for (uint32_t v = 0; v < F.nv; v++) {
+        const int32_t r = rep[2 * v];
+        if (r < 0 || r == (int32_t)(2 * v)) continue;
+        if (r == (int32_t)(2 * v + 1)) { F.unsat = true; return 0; }      // x and ~x in one component
+        if ((r >> 1) > (int32_t)v) continue;                              // (the mirror component decides)
+        map[2 * v] = r;
+        map[2 * v + 1] = r ^ 1;
+        F.subst[v] = r;
+        F.lemma({(int32_t)(2 * v + 1), r});
+        F.lemma({(int32_t)(2 * v), r ^ 1});
+        n_sub++;
+    }
+    if (!n_sub) return 0;
+    F.n_equiv += n_sub;
+    std::vector<int32_t> nl2v, tmp;
+    std::vector<uint64_t> no2{0};
+    nl2v.reserve(F.nl.size());
+    for (size_t c = 0; c < nn && !F.unsat; c++) {
+        tmp.clear();
+        bool changed = false;
+        for (uint64_t k = F.no[c]; k < F.no[c + 1]; k++) { tmp.push_back(map[F.nl[k]]); changed = changed || map[F.nl[k]] != F.nl[k]; }
+        if (changed) {
+            std::vector<int32_t> lem = tmp;
+            std::sort(lem.begin(), lem.end());
+            lem.erase(std::unique(lem.begin(), lem.end()), lem.end());
+            bool taut = false;
+            for (size_t i = 0; i + 1 < lem.size(); i++) taut = taut || (lem[i] ^ 1) == lem[i + 1];
+            if (!taut) F.lemma(lem);
+        }
+        if (!normal_clause(F, tmp)) continue;
+        nl2v.insert(nl2v.end(), tmp.begin(), tmp.end());
+        no2.push_back(nl2v.size());
+    }
+    F.nl.swap(nl2v);
+    F.no.swap(no2);
+    return n_sub;
+}
+
+void launch_probe(mi355sat& s);   // below (needs launch parameters)
+const char* status_text(int st);
+
+// Failed-literal probing on the device (ms_probe_kernel): both polarities of every variable that still occurs.
+uint64_t device_probe(mi355sat& s, Formula& F) {
+    if (F.unsat || F.n_clauses() == 0) return 0;
+    Prepared P;
+    build_csr(s, F, /*units_propagated=*/true, P);
+    std::vector<uint8_t> occurs(F.nv, 0);
+    for (int32_t l : F.nl) occurs[l >> 1] = 1;
+    std::vector<uint32_t> cand;
+    for (uint32_t v = 0; v < F.nv; v++) if (occurs[v] && !F.val[v]) cand.push_back(v);
+    if (cand.empty()) return 0;
+    uint32_t W = (uint32_t)std::min<size_t>(1024, cand.size());
+    std::vector<std::vector<int32_t>> per;
+    std::vector<int32_t> script;
+    std::vector<uint64_t> soff;
+    uint32_t cap = 0;
+    for (;;) {   // as many workers as the device has room for (the script length is part of the slab layout)
+        per.assign(W, {});
+        for (size_t i = 0; i < cand.size(); i++) {
+            const int32_t dl = 2 * (int32_t)P.perm[cand[i]];
+            per[i % W].push_back(dl);
+            per[i % W].push_back(dl ^ 1);
+        }
+        script.clear();
+        soff.assign(1, 0);
+        cap = 0;
+        for (auto& v : per) { script.insert(script.end(), v.begin(), v.end()); soff.push_back(script.size()); cap = std::max<uint32_t>(cap, (uint32_t)v.size()); }
+        upload_formula(s, P, 0, cap, W);
+        if (s.n_workers >= W) break;
+        W = s.n_workers;
+    }
+    reset_workers(s);
+    customize(s, nullptr, nullptr, &script, &soff, W);
+    launch_probe(s);
+    // results
+    std::vector<uint32_t> inv(P.perm.size());
+    for (uint32_t e = 0; e < P.perm.size(); e++) inv[P.perm[e]] = e;
+    auto to_caller = [&](int32_t dl) { return 2 * (int32_t)inv[dl >> 1] | (dl & 1); };
+    const size_t fact_row = 3 * (((size_t)P.n_vars + 1) / 3);
+    std::vector<int32_t> res((size_t)W * cap), facts((size_t)W * std::max<size_t>(fact_row, 1)), nfacts(W);
+    HIPCHK(hipMemcpy2D(res.data(), 4 * (size_t)cap, s.d_slabs.p + s.L.script, s.L.slab_bytes, 4 * (size_t)cap, W, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(nfacts.data(), 4, s.d_slabs.p + s.L.learnt_buf, s.L.slab_bytes, 4, W, hipMemcpyDeviceToHost));
+    if (fact_row) HIPCHK(hipMemcpy2D(facts.data(), 4 * fact_row, s.d_slabs.p + s.L.toclear, s.L.slab_bytes, 4 * fact_row, W, hipMemcpyDeviceToHost));
+    std::vector<MsState> sts;
+    gather_states(s, sts);
+    uint64_t n_new = 0;
+    for (uint32_t w = 0; w < W && !F.unsat; w++) {
+        if (sts[w].status < 0) throw HipErr{std::string("probing: ") + status_text(sts[w].status)};
+        if (sts[w].status == MS_ST_UNSAT) { F.unsat = true; break; }       // conflict among the formula's own units
+        for (size_t d = 0; d < per[w].size(); d++)
+            if (res[(size_t)w * cap + d] == -1) {                          // failed literal: its negation is a fact
+                const int32_t a = to_caller(per[w][d]);
+                if (F.val[a >> 1] == 0) { F.lemma({a ^ 1}); F.n_failed++; n_new++; }
+                if (!F.assign_unit(a ^ 1)) F.unsat = true;
+            }
+        for (int32_t f = 0; f < nfacts[w] && !F.unsat; f++) {
+            const int32_t* t = facts.data() + (size_t)w * fact_row + 3 * (size_t)f;
+            const int32_t m = to_caller(t[1]), a = to_caller(t[2]);
+            if (t[0] == 1) {                                               // a -> m and ~a -> m
+                if (F.val[m >> 1] == 0) { F.lemma({a ^ 1, m}); F.lemma({a, m}); F.lemma({m}); F.n_necessary++; n_new++; }
+                if (!F.assign_unit(m)) F.unsat = true;
+            } else if (t[0] == 2 && (m >> 1) != (a >> 1)) {                // a -> m and ~a -> ~m: m == a, as two binary clauses
+                std::vector<int32_t> c1{a ^ 1, m}, c2{a, m ^ 1};
+                for (auto* c : {&c1, &c2}) {
+                    F.lemma(*c);
+                    if (normal_clause(F, *c)) { F.nl.insert(F.nl.end(), c->begin(), c->end()); F.no.push_back(F.nl.size()); }
+                }
+                n_new++;
+            }
+        }
+    }
+    return n_new;
+}
+
+// Subsumption / self-subsuming resolution on the device (ms_subsume_kernel), applied on the host.
+uint64_t device_subsume(mi355sat& s, Formula& F) {
+    if (F.unsat || F.n_clauses() == 0) return 0;
+    const size_t nn = F.n_clauses();
+    std::vector<unsigned long long> sig(nn, 0);
+    std::vector<uint32_t> occ_off(2 * (size_t)F.nv + 1, 0);
+    for (size_t c = 0; c < nn; c++)
+        for (uint64_t k = F.no[c]; k < F.no[c + 1]; k++) {
+            sig[c] |= 1ull << (((uint32_t)(F.nl[k] >> 1) * 2654435761u) >> 26);
+            occ_off[F.nl[k] + 1]++;
+        }
+    for (size_t i = 0; i < 2 * (size_t)F.nv; i++) occ_off[i + 1] += occ_off[i];
+    std::vector<uint32_t> occ(F.nl.size()), fill(occ_off.begin(), occ_off.end() - 1);
+    for (size_t c = 0; c < nn; c++)
+        for (uint64_t k = F.no[c]; k < F.no[c + 1]; k++) occ[fill[F.nl[k]]++] = (uint32_t)c;
+    DevBuf<int32_t> d_lits, d_drop;
+    DevBuf<uint64_t> d_offs;
+    DevBuf<unsigned long long> d_sig;
+    DevBuf<uint32_t> d_occ_off, d_occ, d_sub;
+    d_lits.upload(F.nl, s.stream);
+    d_offs.upload(F.no, s.stream);
+    d_sig.upload(sig, s.stream);
+    d_occ_off.upload(occ_off, s.stream);
+    d_occ.upload(occ, s.stream);
+    d_sub.alloc(nn);
+    d_drop.alloc(nn);
+    HIPCHK(hipMemsetAsync(d_sub.p, 0, 4 * nn, s.stream));
+    HIPCHK(hipMemsetAsync(d_drop.p, 0xff, 4 * nn, s.stream));
+    hipLaunchKernelGGL(ms_subsume_kernel, dim3((uint32_t)((nn + 255) / 256)), dim3(256), 0, s.stream, (uint32_t)nn, d_lits.p, d_offs.p,
+                       d_sig.p, d_occ_off.p, d_occ.p, 64u, d_sub.p, d_drop.p);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> sub(nn);
+    std::vector<int32_t> drop(nn);
+    HIPCHK(hipMemcpyAsync(sub.data(), d_sub.p, 4 * nn, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipMemcpyAsync(drop.data(), d_drop.p, 4 * nn, hipMemcpyDeviceToHost, s.stream));
+    HIPCHK(hipStreamSynchronize(s.stream));
+    uint64_t n = 0;
+    std::vector<int32_t> nl2, tmp;
+    std::vector<uint64_t> no2{0};
+    nl2.reserve(F.nl.size());
+    for (size_t c = 0; c < nn && !F.unsat; c++) {
+        if (sub[c]) { F.n_subsumed++; n++; continue; }
+        tmp.assign(F.nl.begin() + F.no[c], F.nl.begin() + F.no[c + 1]);
+        if (drop[c] >= 0) {
+            tmp.erase(std::remove(tmp.begin(), tmp.end(), drop[c]), tmp.end());
+            F.lemma(tmp);
+            F.n_strengthened++;
+            n++;
+            if (!normal_clause(F, tmp)) continue;
+        }
+        nl2.insert(nl2.end(), tmp.begin(), tmp.end());
+        no2.push_back(nl2.size());
+    }
+    F.nl.swap(nl2);
+    F.no.swap(no2);
+    return n;
+}
+
+// The whole pipeline: units, then rounds of {equivalent literals, probing} while they find something, then
+// subsumption.  Everything it derives is a consequence of the caller's formula alone (never of assumptions).
+void simplify_formula(mi355sat& s, Formula& F) {
+    propagate_units(F);
+    if (s.opts.simp < 0 || F.unsat) return;
+    const double t0 = now_s();
+    const size_t c0 = F.n_clauses(), l0 = F.nl.size(), u0 = F.units.size();
+    for (int round = 0; round < 3 && !F.unsat; round++) {
+        uint64_t n = els_scc(F);
+        propagate_units(F);
+        n += device_probe(s, F);
+        propagate_units(F);
+        if (!n) break;
+    }
+    for (int pass = 0; pass < 3 && !F.unsat; pass++) {
+        const uint64_t n = device_subsume(s, F);
+        propagate_units(F);
+        if (!n) break;
+    }
+    if (s.opts.verbose)
+        fprintf(stderr, "[mi355sat] simplification %.3f s: clauses %zu -> %zu, literals %zu -> %zu, units +%zu (failed literals %llu, necessary %llu), "
+                "equivalent variables %llu, subsumed %llu, strengthened %llu%s\n", now_s() - t0, c0, F.n_clauses(), l0, F.nl.size(),
+                F.units.size() - u0, (unsigned long long)F.n_failed, (unsigned long long)F.n_necessary, (unsigned long long)F.n_equiv,
+                (unsigned long long)F.n_subsumed, (unsigned long long)F.n_strengthened, F.unsat ? " - UNSAT" : "");
+}
+
 void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
     mi355sat_stats_t& o = s.stats;
     uint64_t learnts = 0, llits = 0;
@@ -772,7 +1117,6 @@ void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
     uint64_t exported = 0, imported = 0, imported_units = 0;
     for (auto& st : sts) { exported += st.n_exported; imported += st.n_imported; imported_units += st.n_imported_units; }
     o.shared_exported += exported; o.shared_imported += imported; o.shared_imported_units += imported_units;
-    for (int i = 0; i < 3; i++) o.reserved[i] = 0;
     uint64_t prof[10] = {0}, cyc = 0;
     for (auto& st : sts) { for (int i = 0; i < 10; i++) prof[i] += st.prof[i]; cyc += st.slice_cycles; }
     if (prof[0] && s.opts.verbose) {
@@ -791,8 +1135,11 @@ void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_
         HIPCHK(hipMemcpy(words.data(), s.d_slabs.p + (size_t)worker * s.L.slab_bytes + s.L.val,
                          4 * (((size_t)s.n_vars + 15) / 16), hipMemcpyDeviceToHost));
     out.assign(n_vars_out, 0);
-    for (uint64_t v = 0; v < n_vars_out && v < s.n_vars; v++)
-        out[v] = asg_of(words.data(), s.perm[v]) == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
+    for (uint64_t v = 0; v < n_vars_out && v < s.n_vars; v++) {
+        const int32_t r = v < s.subst.size() ? s.subst[v] : 2 * (int32_t)v;
+        if (r != 2 * (int32_t)v && (uint64_t)(r >> 1) < v) out[v] = (r & 1) ? (int8_t)-out[r >> 1] : out[r >> 1];   // representatives have smaller indices
+        else out[v] = asg_of(words.data(), s.perm[v]) == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
+    }
 }
 
 struct SliceResult { float ms; };
@@ -846,6 +1193,9 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
             if (one) hipLaunchKernelGGL((ms_search_kernel<false, true>), dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
             else hipLaunchKernelGGL((ms_search_kernel<false, false>), dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
         }
+    } else if (mode == 2) {
+        if (lds) hipLaunchKernelGGL(ms_probe_kernel<true>, dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+        else hipLaunchKernelGGL(ms_probe_kernel<false>, dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
     } else {
         if (lds) hipLaunchKernelGGL(ms_bcp_kernel<true>, dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
         else hipLaunchKernelGGL(ms_bcp_kernel<false>, dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
@@ -869,10 +1219,16 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     return SliceResult{ms};
 }
 
+void launch_probe(mi355sat& s) { launch_slice(s, 2, false); }
+
 // DRUP text: one learnt clause per line in derivation order (DIMACS literals), then the empty clause.
 void write_proof(mi355sat& s, bool unsat) {
     FILE* f = fopen(s.proof_path.c_str(), "w");
     if (!f) throw HipErr{"cannot open proof file " + s.proof_path};
+    for (int32_t l : s.simp_proof) {   // what the simplification derived, in its order (caller's numbering already)
+        if (l < 0) fputs("0\n", f);
+        else fprintf(f, "%d ", (l & 1) ? -((l >> 1) + 1) : ((l >> 1) + 1));
+    }
     uint32_t n = 0;
     if (s.d_proof_len.p) HIPCHK(hipMemcpy(&n, s.d_proof_len.p, sizeof n, hipMemcpyDeviceToHost));
     if (n > s.d_proof.n) { fclose(f); throw HipErr{"proof buffer overflow (derivation too long to log)"}; }
@@ -928,7 +1284,18 @@ struct Sweep {
 int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, const std::vector<uint64_t>& assump_off,
                 uint32_t n_instances, bool stop_at_first) {
     Prepared P;
-    prepare(s, /*simplify=*/true, P);
+    {
+        Formula F;
+        normalise(s, F);
+        F.log_proof = !s.proof_path.empty();
+        simplify_formula(s, F);
+        build_csr(s, F, /*units_propagated=*/true, P);
+        s.subst = F.subst;
+        s.simp_proof.swap(F.proof);
+        s.stats.simp_units = F.n_failed + F.n_necessary;
+        s.stats.simp_equivalences = F.n_equiv;
+        s.stats.simp_clauses_removed = F.n_subsumed + F.n_strengthened;
+    }
     sw.n_instances = n_instances;
     sw.stop_at_first = stop_at_first;
     sw.decided = 0;
@@ -964,7 +1331,9 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     for (size_t i = 0; i < assump.size(); i++) {
         int32_t d = assump[i];
         if (d == 0 || (uint64_t)(d < 0 ? -(int64_t)d : d) > P.n_vars) throw HipErr{"assumption literal out of range"};
-        a_int[i] = to_device(P.perm, d);
+        int32_t l = to_internal(d);
+        while (s.subst[l >> 1] != 2 * (l >> 1)) l = s.subst[l >> 1] ^ (l & 1);     // a variable replaced by an equivalent literal
+        a_int[i] = 2 * (int32_t)P.perm[l >> 1] | (l & 1);
     }
     uint32_t max_assumps = 0;
     for (uint32_t i = 0; i < n_instances; i++)
