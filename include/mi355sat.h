@@ -220,9 +220,12 @@ int mi355sat_stats(const mi355sat* s, mi355sat_stats_t* out);
  * too small. */
 int mi355sat_debug_share_ring(mi355sat* s, int32_t* out, uint64_t cap_words, uint64_t* n_records);
 
-/* Optional DRUP proof (text, DIMACS literals, one learnt clause per line in derivation order, the
- * empty clause last) of the next plain solve().  Logging makes that solve use ONE worker (a proof is
- * the derivation of one search).  Must be called before solve(); path NULL disables. */
+/* Optional DRUP proof (text, DIMACS literals, one lemma per line, the empty clause last) of the next plain
+ * solve(), in its default configuration: all workers, clause exchange on.  Order of the lines: what the
+ * simplification derived, then after every kernel slice the clauses each worker learnt in it; every line is a
+ * RUP consequence of the lines before it (the exchange only hands on clauses of earlier slices).  No deletion
+ * lines: a clause one worker drops may still be held by another.  Must be called before solve(); path NULL
+ * disables. */
 int mi355sat_set_proof_path(mi355sat* s, const char* path);
 
 #ifdef __cplusplus

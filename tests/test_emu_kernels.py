@@ -153,17 +153,21 @@ def test_emulated_cube_splitting_partitions_the_search_space():
 
 
 def test_emulated_unsat_verdicts_carry_a_drup_proof(tmp_path):
-    """The device logs its learnt clauses; the oracle's independent RUP checker must accept the proof."""
+    """Every worker logs the clauses it learns (the default configuration: several workers, clause exchange on); the
+    host interleaves the logs slice by slice; the oracle's independent RUP checker must accept the proof."""
     from timberborn_support_solver_amd.dimacs import read_drup, read_dimacs, write_dimacs
-    for terrain, pset, k in [("ex1", "1x1", 2), ("rect8x8", "default", 1)]:
+    exchanged = 0
+    for terrain, pset, k in [("ex1", "1x1", 2), ("rect8x8", "default", 1), ("rect8x8", "1x1", 3)]:
         grid = make_grid(terrain)
         enc = Encoding.encode(platform_defs(pset), grid)
         cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
         proof = str(tmp_path / "p.drup")
-        s = emu_solver(workers=8, slice_conflicts=1000)
+        s = emu_solver(workers=8, slice_conflicts=8)
         s.set_proof_path(proof)
         s.add_cnf(cnf.lits, cnf.offsets)
         assert s.solve() == SolverResult.Unsat
+        st = s.stats()
+        exchanged += st["shared_imported"] + st["shared_imported_units"]
         s.close()
         assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof)) == 1
         # DIMACS round trip of the same CNF
@@ -171,6 +175,7 @@ def test_emulated_unsat_verdicts_carry_a_drup_proof(tmp_path):
         write_dimacs(path, cnf.lits, cnf.offsets, cnf.n_vars)
         l2, o2, nv2 = read_dimacs(path)
         assert nv2 == cnf.n_vars and np.array_equal(l2, cnf.lits) and np.array_equal(o2, cnf.offsets)
+    assert exchanged > 0      # the proofs above include derivations that used other workers' clauses
 
 
 def test_emulated_weight_loop_like_the_gui():

@@ -166,8 +166,9 @@ def test_cube_splitting_mode_gives_the_same_verdicts():
 @pytest.mark.parametrize("terrain,pset,k", [("ex3", "1x1", 3), ("rect8x8", "default", 1), ("rect16x16", "default", 3),
                                              ("rect16x16", "1x1", 10)])
 def test_unsat_verdicts_carry_a_checked_drup_proof(tmp_path, terrain, pset, k):
-    """UNSAT parity beyond agreement of solvers: the GPU's own derivation (DRUP log of its learnt
-    clauses) is verified by the oracle's forward RUP checker."""
+    """UNSAT parity beyond agreement of solvers: the GPU's own derivation (DRUP log of the clauses ALL its workers
+    learnt, in the default configuration: simplification, the default fleet, clause exchange on) is verified by the
+    oracle's forward RUP checker against the caller's formula."""
     from timberborn_support_solver_amd.dimacs import read_drup
     grid = make_grid(terrain)
     enc = Encoding.encode(platform_defs(pset), grid)
@@ -177,8 +178,11 @@ def test_unsat_verdicts_carry_a_checked_drup_proof(tmp_path, terrain, pset, k):
     s.set_proof_path(proof)
     s.add_cnf(cnf.lits, cnf.offsets)
     assert s.solve() == SolverResult.Unsat
+    st = s.stats()
     s.close()
     assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof)) == 1
+    if (terrain, pset, k) == ("rect16x16", "1x1", 10):       # long enough for the exchange to matter
+        assert st["shared_imported"] + st["shared_imported_units"] > 0
 
 
 def test_cpp_solver_loop_cli_prints_the_reference_messages():

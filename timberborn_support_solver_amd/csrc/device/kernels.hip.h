@@ -1401,7 +1401,9 @@ __global__ __launch_bounds__(MS_WAVE, ONE ? 1 : MS_SEARCH_WAVES_PER_SIMD) void m
     ls.learnt_total = st->learnt_total; ls.learnt_lits_total = st->learnt_lits_total;
     ls.lbdq_n = st->lbdq_n; ls.lbdq_i = st->lbdq_i; ls.trail_avg = st->trail_avg;
     ls.n_assumps = st->n_assumps; ls.lbdq = s_lbdq;
-    ls.proof_buf = wid == 0 ? prm.proof_buf : nullptr; ls.proof_len = prm.proof_len; ls.proof_cap = prm.proof_cap;
+    // DRUP: every worker logs the clauses it learns into its own buffer; the host drains all of them after each slice
+    ls.proof_buf = prm.proof_buf ? prm.proof_buf + (size_t)wid * prm.proof_cap : nullptr;
+    ls.proof_len = prm.proof_len + wid; ls.proof_cap = prm.proof_cap;
     ls.share_pool = (const int4*)prm.share_pool;
     ls.share_n = prm.share_pool ? *prm.share_n : 0;
     ls.share_pos = st->share_pos; ls.n_exported = st->n_exported; ls.n_imported = st->n_imported;

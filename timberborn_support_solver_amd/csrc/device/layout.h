@@ -172,8 +172,8 @@ struct MsParams {
     int32_t done_on_refuted;       // a refuted cube also raises any_done (portfolio mode: it decides the instance)
     int32_t pad;
     uint32_t reduce_first, reduce_inc;
-    int32_t* proof_buf;            // optional DRUP log of worker 0: learnt clauses as internal literals, -1 terminated
-    uint32_t* proof_len;           // words used / wanted (the host detects overflow by proof_len > proof_cap)
+    int32_t* proof_buf;            // optional DRUP log: proof_cap words per worker; learnt clauses as internal literals, -1 terminated
+    uint32_t* proof_len;           // per worker: words used / wanted since the last drain (overflow: proof_len > proof_cap)
     uint32_t proof_cap, pad2;
     // clause exchange (share_pool == nullptr: off)
     const int32_t* share_pool;     // ring of share_slots records

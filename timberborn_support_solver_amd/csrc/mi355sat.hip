@@ -335,6 +335,8 @@ struct mi355sat {
     DevBuf<MsState> d_states;
     DevBuf<int32_t> d_any_done, d_assump, d_script, d_proof;
     DevBuf<uint32_t> d_proof_len;
+    uint32_t proof_cap = 0;                    // words per worker in d_proof
+    FILE* proof_file = nullptr;                // open while a solve logs its DRUP proof
     DevBuf<uint64_t> d_assump_off, d_script_off;
     // learnt-clause exchange between workers (layout.h MS_SHARE_*)
     DevBuf<int32_t> d_share_pool;
@@ -760,9 +762,9 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     if (s.opts.verbose) fprintf(stderr, "[mi355sat] slab allocation %.1f GiB (%u of %u workers): %.3f s\n", (double)A * s.L.slab_bytes / 1073741824.0, A, W, now_s() - t_alloc0);
     s.d_states.alloc(W);
     s.d_any_done.alloc(1);
-    // clause exchange: on unless switched off, whenever there is more than one worker and no proof is logged
+    // clause exchange: on unless switched off, whenever there is more than one worker
     s.share_slots = 0;
-    if (s.opts.share >= 0 && W > 1 && s.proof_path.empty() && script_cap == 0) {
+    if (s.opts.share >= 0 && W > 1 && script_cap == 0) {
         s.share_slots = 1u << 19;   // 64 MiB of records
         while ((uint64_t)s.share_slots < (uint64_t)W * MS_EXPORT_RECS) s.share_slots <<= 1;   // one collection (<= W * MS_EXPORT_RECS
                                                                                               // records) never wraps onto itself
@@ -1160,7 +1162,7 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     prm.done_on_refuted = done_on_refuted ? 1 : 0;
     prm.proof_buf = s.d_proof.p;
     prm.proof_len = s.d_proof_len.p;
-    prm.proof_cap = (uint32_t)s.d_proof.n;
+    prm.proof_cap = s.proof_cap;
     prm.reduce_first = s.opts.reduce_first > 0 ? (uint32_t)s.opts.reduce_first : 2000u;
     prm.reduce_inc = s.opts.reduce_inc > 0 ? (uint32_t)s.opts.reduce_inc : 300u;
     const bool share = mode == 0 && s.share_slots != 0;
@@ -1221,27 +1223,45 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
 
 void launch_probe(mi355sat& s) { launch_slice(s, 2, false); }
 
-// DRUP text: one learnt clause per line in derivation order (DIMACS literals), then the empty clause.
-void write_proof(mi355sat& s, bool unsat) {
-    FILE* f = fopen(s.proof_path.c_str(), "w");
-    if (!f) throw HipErr{"cannot open proof file " + s.proof_path};
-    for (int32_t l : s.simp_proof) {   // what the simplification derived, in its order (caller's numbering already)
-        if (l < 0) fputs("0\n", f);
-        else fprintf(f, "%d ", (l & 1) ? -((l >> 1) + 1) : ((l >> 1) + 1));
+// DRUP text (DIMACS literals, one lemma per line).  Order: what the simplification derived, then after every
+// slice the clauses each worker learnt in it (worker by worker, each in its own derivation order), finally the empty
+// clause.  That order makes every line a RUP consequence of the lines before it: a learnt clause depends on its
+// worker's earlier clauses and on exchanged clauses, and the exchange only hands on clauses of EARLIER slices.
+void proof_open(mi355sat& s) {
+    s.proof_file = fopen(s.proof_path.c_str(), "w");
+    if (!s.proof_file) throw HipErr{"cannot open proof file " + s.proof_path};
+    for (int32_t l : s.simp_proof) {   // (caller's numbering already)
+        if (l < 0) fputs("0\n", s.proof_file);
+        else fprintf(s.proof_file, "%d ", (l & 1) ? -((l >> 1) + 1) : ((l >> 1) + 1));
     }
-    uint32_t n = 0;
-    if (s.d_proof_len.p) HIPCHK(hipMemcpy(&n, s.d_proof_len.p, sizeof n, hipMemcpyDeviceToHost));
-    if (n > s.d_proof.n) { fclose(f); throw HipErr{"proof buffer overflow (derivation too long to log)"}; }
-    std::vector<int32_t> buf(n);
-    if (n) HIPCHK(hipMemcpy(buf.data(), s.d_proof.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+}
+void proof_drain(mi355sat& s) {
+    if (!s.proof_file || !s.d_proof_len.p) return;
+    const uint32_t W = (uint32_t)s.d_proof_len.n;
+    std::vector<uint32_t> len(W);
+    HIPCHK(hipMemcpy(len.data(), s.d_proof_len.p, sizeof(uint32_t) * W, hipMemcpyDeviceToHost));
     std::vector<uint32_t> inv(s.perm.size());
     for (uint32_t e = 0; e < s.perm.size(); e++) inv[s.perm[e]] = e;
-    for (uint32_t i = 0; i < n; i++) {
-        if (buf[i] < 0) fputs("0\n", f);
-        else fprintf(f, "%d ", (buf[i] & 1) ? -((int)inv[buf[i] >> 1] + 1) : ((int)inv[buf[i] >> 1] + 1));
+    std::vector<int32_t> buf;
+    bool any = false;
+    for (uint32_t w = 0; w < W; w++) {
+        if (!len[w]) continue;
+        any = true;
+        if (len[w] > s.proof_cap) throw HipErr{"proof buffer overflow (a worker learnt more in one slice than its log holds)"};
+        buf.resize(len[w]);
+        HIPCHK(hipMemcpy(buf.data(), s.d_proof.p + (size_t)w * s.proof_cap, sizeof(int32_t) * len[w], hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < len[w]; i++) {
+            if (buf[i] < 0) fputs("0\n", s.proof_file);
+            else fprintf(s.proof_file, "%d ", (buf[i] & 1) ? -((int)inv[buf[i] >> 1] + 1) : ((int)inv[buf[i] >> 1] + 1));
+        }
     }
-    if (unsat) fputs("0\n", f);
-    fclose(f);
+    if (any) { HIPCHK(hipMemsetAsync(s.d_proof_len.p, 0, sizeof(uint32_t) * W, s.stream)); HIPCHK(hipStreamSynchronize(s.stream)); }
+}
+void proof_close(mi355sat& s, bool unsat) {
+    if (!s.proof_file) return;
+    if (unsat) fputs("0\n", s.proof_file);
+    fclose(s.proof_file);
+    s.proof_file = nullptr;
 }
 
 const char* status_text(int st) {
@@ -1296,6 +1316,10 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
         s.stats.simp_equivalences = F.n_equiv;
         s.stats.simp_clauses_removed = F.n_subsumed + F.n_strengthened;
     }
+    if (!s.proof_path.empty()) {
+        if (n_instances != 1) throw HipErr{"a proof can only be logged for a plain solve()"};
+        proof_open(s);
+    }
     sw.n_instances = n_instances;
     sw.stop_at_first = stop_at_first;
     sw.decided = 0;
@@ -1315,17 +1339,11 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     // with 1024 workers (rect 24x24 ladder), small ones do not pay for more than one worker per CU
     uint32_t want = s.opts.workers > 0 ? (uint32_t)s.opts.workers
                                        : (s.offs.size() > 100000 ? MS_SEARCH_WAVES_PER_SIMD * 1024u : (s.offs.size() > 20000 ? 1024u : 256u));
-    if (!s.proof_path.empty()) want = 1;   // a DRUP proof is the derivation of ONE search: worker 0 alone
     if (want < n_instances) want = n_instances;
     want = want / n_instances * n_instances;
     s.d_proof.release();
     s.d_proof_len.release();
-    if (!s.proof_path.empty()) {
-        if (n_instances != 1) throw HipErr{"a proof can only be logged for a plain solve()"};
-        s.d_proof.alloc((size_t)64 << 20);
-        s.d_proof_len.alloc(1);
-        HIPCHK(hipMemsetAsync(s.d_proof_len.p, 0, sizeof(uint32_t), s.stream));
-    }
+    s.proof_cap = 0;
     sw.split = s.opts.cube_split > 0 && want > n_instances;   // opt-in: see DESIGN.md (measured: not yet a win)
     std::vector<int32_t> a_int(assump.size());
     for (size_t i = 0; i < assump.size(); i++) {
@@ -1344,6 +1362,12 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     if (s.n_workers < n_instances) throw HipErr{"not enough device memory for one worker per instance"};
     s.n_workers = s.n_workers / n_instances * n_instances;
     s.n_alloc = std::min(s.n_alloc, s.n_workers);
+    if (!s.proof_path.empty()) {   // one log per worker, drained after every slice (4 MiB each: ~10^4 learnt clauses per slice)
+        s.proof_cap = 1u << 20;
+        s.d_proof.alloc((size_t)s.n_workers * s.proof_cap);
+        s.d_proof_len.alloc(s.n_workers);
+        HIPCHK(hipMemsetAsync(s.d_proof_len.p, 0, sizeof(uint32_t) * s.n_workers, s.stream));
+    }
     reset_workers(s);
     customize(s, &a_int, &assump_off, nullptr, nullptr, n_instances, sw.split ? (int32_t)n_instances : -1);
     HIPCHK(hipStreamSynchronize(s.stream));
@@ -1494,6 +1518,7 @@ int sweep_step(mi355sat& s, Sweep& sw) {
     if (active > s.n_alloc) grow_workers(s, n_instances, active);
     SliceResult sr = launch_slice(s, 0, /*stop_on_any=*/n_instances == 1 || sw.stop_at_first, /*done_on_refuted=*/!sw.split, active);
     sw.ramp_ms += sr.ms;
+    proof_drain(s);
     gather_states(s, sw.sts);
     int rc = 0;
     uint64_t confl = 0;
@@ -1642,6 +1667,7 @@ void mi355sat_free(mi355sat* s) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     delete s->sweep;
+    if (s->proof_file) fclose(s->proof_file);
     s->d_cl_lits.release(); s->d_bin_lits.release();
     s->d_tern_pairs.release(); s->d_tern_owner.release();
     s->d_template.release(); s->d_slabs.release(); s->d_states.release(); s->d_any_done.release();
@@ -1724,10 +1750,11 @@ int mi355sat_solve(mi355sat* s) {
         int rc = run_search(*s, assump, aoff, 1, results, winner, true);
         if (rc) { s->stats.solve_seconds += now_s() - t0; return rc; }
         result = results[0];
-        if (!s->proof_path.empty()) write_proof(*s, result == MI355SAT_UNSAT);
+        proof_close(*s, result == MI355SAT_UNSAT);
         s->model.clear();
         if (result == MI355SAT_SAT) fetch_model(*s, (uint32_t)winner[0], s->model, s->max_var);
     } catch (HipErr& he) {
+        proof_close(*s, false);
         s->err = he.msg;
         s->stats.solve_seconds += now_s() - t0;
         return MI355SAT_ERR_HIP;
