@@ -94,6 +94,8 @@ typedef struct mi355sat_opts {
                                   (on): equivalent-literal substitution, failed-literal probing on the device, subsumption and
                                   self-subsuming resolution on the device; -1 = only level-0 unit propagation.  Invisible at this
                                   interface: models, assumptions and proofs stay in the caller's variables. */
+    int32_t phase_mix;         /* 0 = default: every worker starts with all saved phases FALSE (no platform anywhere);
+                                  1 = portfolio of initial phases: a quarter of the workers start TRUE, a quarter at random */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
 } mi355sat_opts;

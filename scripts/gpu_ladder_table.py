@@ -10,11 +10,14 @@ from timberborn_support_solver_amd import (Encoding, Mi355Sat, PlatformLayout, P
 from timberborn_support_solver_amd.encoder import PLATFORMS_DEFAULT  # noqa: E402
 
 sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [16, 20, 24, 26]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+limit = float(sys.argv[3]) if len(sys.argv) > 3 else 150
+cpu_limit = float(sys.argv[4]) if len(sys.argv) > 4 else 240
 for m in sizes:
     g = WorldGrid.rect(m, m)
     e = Encoding.encode(PLATFORMS_DEFAULT, g)
     k, tc, kstar, confl = m, time.perf_counter(), None, 0
-    while time.perf_counter() - tc < 240:
+    while time.perf_counter() - tc < cpu_limit:
         ck = e.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
         o = ora.OracleSolver()
         o.add_cnf(ck.lits, ck.offsets)
@@ -29,9 +32,9 @@ for m in sizes:
     cpu_s = time.perf_counter() - tc
     print(f"rect {m}: CPU done in {cpu_s:.1f} s", flush=True)   # (keeps a long rung from looking hung)
     gpu = []
-    for rep in range(3):
+    for rep in range(reps):
         t0 = time.perf_counter()
-        hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=150, make_solver=lambda: Mi355Sat(slice_ms=10))
+        hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=limit, make_solver=lambda: Mi355Sat(slice_ms=10))
         ok = hist[-1]["result"] == SolverResult.Unsat
         gpu.append((round(time.perf_counter() - t0, 2), [h["count"] for h in hist if h["count"]][-1] if ok else None))
         print(f"rect {m}: GPU run {rep} {gpu[-1]}", flush=True)

@@ -17,9 +17,13 @@ __global__ void chase(const uint32_t* __restrict__ next, uint32_t n, uint32_t st
     if (i == 0xffffffffu) out[0] = i;   // keep the chain alive
 }
 
-int main() {
+// chase MB W STEPS: ONE configuration, for calibrating rocprofv3's FETCH_SIZE on this access pattern (every dependent
+// load touches one random 64-byte line: W * 64 * STEPS lines in the timed launch, printed as "expected bytes").
+int main(int argc, char** argv) {
     std::mt19937_64 rng(1);
-    for (size_t mb : {8, 256, 8192, 65536}) {
+    const bool one = argc == 4;
+    std::vector<size_t> sizes = one ? std::vector<size_t>{(size_t)atol(argv[1])} : std::vector<size_t>{8, 256, 8192, 65536};
+    for (size_t mb : sizes) {
         const size_t n = mb * 1024 * 1024 / 64;          // one entry per 64-byte line
         std::vector<uint32_t> perm(n), next(n * 16, 0);
         std::iota(perm.begin(), perm.end(), 0u);
@@ -29,8 +33,9 @@ int main() {
         if (hipMalloc(&d_next, next.size() * 4) != hipSuccess) { printf("alloc %zu MiB failed\n", mb); continue; }
         (void)hipMalloc(&d_out, 4);
         (void)hipMemcpy(d_next, next.data(), next.size() * 4, hipMemcpyHostToDevice);
-        for (int W : {1, 256, 1024, 4096, 8192}) {
-            const uint32_t steps = W >= 1024 ? 2000 : 20000;
+        std::vector<int> ws = one ? std::vector<int>{atoi(argv[2])} : std::vector<int>{1, 256, 1024, 4096, 8192};
+        for (int W : ws) {
+            const uint32_t steps = one ? (uint32_t)atol(argv[3]) : (W >= 1024 ? 2000 : 20000);
             hipEvent_t e0, e1;
             (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             hipLaunchKernelGGL(chase, dim3(W), dim3(64), 0, 0, d_next, (uint32_t)(n * 16), 100u, d_out);   // warm-up
@@ -42,6 +47,7 @@ int main() {
             (void)hipEventElapsedTime(&ms, e0, e1);
             printf("buffer %6zu MiB, %4d waves x 64 lanes (64 independent chains per wave): %8.1f ns per dependent load, %7.1f GB/s of 64-byte lines\n",
                    mb, W, ms * 1e6 / steps, (double)W * 64 * steps * 64 / (ms * 1e-3) / 1e9);
+            if (one) printf("expected bytes of the timed launch (64-byte lines): %.0f\n", (double)W * 64 * steps * 64);
         }
         (void)hipFree(d_next); (void)hipFree(d_out);
     }

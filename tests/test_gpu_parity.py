@@ -174,14 +174,17 @@ def test_unsat_verdicts_carry_a_checked_drup_proof(tmp_path, terrain, pset, k):
     enc = Encoding.encode(platform_defs(pset), grid)
     cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
     proof = str(tmp_path / "p.drup")
-    s = Mi355Sat()
+    # the long refutation with 16 workers: the proof holds every worker's clauses and the oracle's checker is a
+    # plain occurrence-list propagator (the default fleet's log of this one takes it many minutes)
+    long_one = (terrain, pset, k) == ("rect16x16", "1x1", 10)
+    s = Mi355Sat(workers=16, slice_ms=5) if long_one else Mi355Sat()
     s.set_proof_path(proof)
     s.add_cnf(cnf.lits, cnf.offsets)
     assert s.solve() == SolverResult.Unsat
     st = s.stats()
     s.close()
     assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof)) == 1
-    if (terrain, pset, k) == ("rect16x16", "1x1", 10):       # long enough for the exchange to matter
+    if long_one:       # long enough for the exchange to matter: the checked derivation used other workers' clauses
         assert st["shared_imported"] + st["shared_imported_units"] > 0
 
 

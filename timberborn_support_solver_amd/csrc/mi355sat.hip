@@ -47,7 +47,7 @@ struct HipErr { std::string msg; };
 __global__ void ms_customize_kernel(MsLayout L, char* slabs, uint32_t n_workers, const int32_t* assump_data,
                                     const uint64_t* assump_off, const int32_t* script_data,
                                     const uint64_t* script_off, uint32_t n_instances, uint64_t seed, int32_t park_from,
-                                    uint32_t wid0) {
+                                    uint32_t wid0, int32_t phase_mix) {
     const uint32_t wid = blockIdx.x + wid0;   // workers [wid0, n_workers)
     if (wid >= n_workers) return;
     char* slab = slabs + (size_t)wid * L.slab_bytes;
@@ -87,10 +87,15 @@ __global__ void ms_customize_kernel(MsLayout L, char* slabs, uint32_t n_workers,
         }
         int32_t* order = (int32_t*)(slab + L.vm_order);
         MsVarRec* vrec = (MsVarRec*)(slab + L.vrec);
+        // initial saved phases (phase_mix): replica % 4 == 1 decides every variable TRUE first, == 2 at random;
+        // the others keep FALSE (the template)
+        const uint32_t pm = phase_mix > 0 ? replica & 3u : 0u;
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
             uint32_t v = (uint32_t)(((uint64_t)a * i + b) % n);
             order[i] = (int32_t)v;
             vrec[v].vm_pos = (int32_t)i;
+            if (pm == 1) vrec[v].phase = 0;
+            else if (pm == 2) vrec[v].phase = (uint8_t)((((uint64_t)v * 0x9E3779B97F4A7C15ull + z) >> 40) & 1);
         }
     }
 }
@@ -815,7 +820,7 @@ void customize(mi355sat& s, const std::vector<int32_t>* assump, const std::vecto
     hipLaunchKernelGGL(ms_customize_kernel, dim3(s.n_alloc), dim3(256), 0, s.stream, s.L, s.d_slabs.p,
                        s.n_alloc, assump_off ? s.d_assump.p : nullptr, assump_off ? s.d_assump_off.p : nullptr,
                        script_off ? s.d_script.p : nullptr, script_off ? s.d_script_off.p : nullptr, n_instances,
-                       s.opts.seed, park_from, 0u);
+                       s.opts.seed, park_from, 0u, s.opts.phase_mix);
     HIPCHK(hipGetLastError());
 }
 
@@ -837,7 +842,7 @@ void grow_workers(mi355sat& s, uint32_t n_instances, uint32_t target) {
     replicate_template(s, old, s.n_alloc);
     hipLaunchKernelGGL(ms_customize_kernel, dim3(s.n_alloc - old), dim3(256), 0, s.stream, s.L, s.d_slabs.p, s.n_alloc,
                        s.d_assump.p, s.d_assump_off.p, (const int32_t*)nullptr, (const uint64_t*)nullptr, n_instances, s.opts.seed,
-                       -1, old);
+                       -1, old, s.opts.phase_mix);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s.stream));
     if (s.opts.verbose) fprintf(stderr, "[mi355sat] grew from %u to %u worker slabs (%.1f GiB): %.3f s\n", old, s.n_alloc,
