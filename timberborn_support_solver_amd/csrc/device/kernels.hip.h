@@ -72,6 +72,8 @@ struct Wk {
     volatile uint32_t* hist;   // 64 words, reduce_db; also the scratch of flat_setup (BCP)
     volatile uint32_t* lval;   // packed assignment, 2 bits per variable (LV variants)
     volatile uint32_t* lseen;  // conflict analysis' "seen" marks, 1 bit per variable (LV variants; all zero between analyses)
+    volatile uint32_t* lcur;   // (LV) variables assigned at the CURRENT decision level (level > 0)
+    volatile uint32_t* lzero;  // (LV) variables assigned at level 0
     volatile int32_t* bfl;     // the false literal of each lane group of the current BCP step
     // hot uniform scalars
     int lane;
@@ -96,6 +98,7 @@ struct Wk {
 #define WK_PTR(T, w, L, field) ((T*)((w).slab + (L).field))
 #define WKA(T, field) ((T*)(w.slab + L.field))
 #define VREC WKA(MsVarRec, vrec)
+#define VMPOS WKA(int32_t, vm_pos)
 
 DEV u64 ballot(bool p) { return __ballot(p); }
 DEV int popc64(u64 m) { return __popcll(m); }
@@ -179,13 +182,25 @@ DEV void ring_note_growth(Wk& w, const MsShared& sh, const MsLayout& L) {
 }
 
 // all lanes call with identical arguments
+// (LV) which level a variable was assigned at, as far as conflict analysis cares: level 0, the current one, or lower
 template <bool LV>
-DEV void enqueue_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int lit, int reason) {
+DEV void level_mark(Wk& w, int v) {
+    if (!LV) return;
+    if (w.n_levels == 0) atomicOr((uint32_t*)&w.lzero[v >> 5], 1u << (v & 31));
+    else atomicOr((uint32_t*)&w.lcur[v >> 5], 1u << (v & 31));
+}
+DEV MsVarRec var_rec(int level, int reason, uint32_t start, uint32_t size, int lit) {
+    return MsVarRec{level, reason, start, (uint16_t)(size > 0xffffu ? 0u : size), (uint8_t)(lit & 1), 0};
+}
+
+template <bool LV>
+DEV void enqueue_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int lit, int reason, uint32_t start = 0, uint32_t size = 0) {
     wave_fence();  // every lane has finished reading the old assignment
     if (w.lane == 0) {
         int v = lit >> 1;
         asg_set<LV>(w, sh, L, lit);
-        *(MsVarHead*)&VREC[v] = MsVarHead{w.n_levels, reason, (uint32_t)(lit & 1)};
+        level_mark<LV>(w, v);
+        VREC[v] = var_rec(w.n_levels, reason, start, size, lit);
         WKA(int32_t, trail)[w.trail_n] = lit;
         w.ring[w.trail_n & (MS_LDS_RING - 1)] = lit;
     }
@@ -221,14 +236,15 @@ DEV int claim_insert(Wk& w, bool want, int q) {
 
 // Winners append their literal to the trail (prefix popcount) and record level / reason.
 template <bool LV>
-DEV void assign_winners(Wk& w, const MsShared& sh, const MsLayout& L, bool won, int q, int reason) {
+DEV void assign_winners(Wk& w, const MsShared& sh, const MsLayout& L, bool won, int q, int reason, uint32_t start = 0, uint32_t size = 0) {
     const u64 wm = ballot(won);
     if (wm == 0) return;
     if (won) {
         const int v = q >> 1;
         const int t = w.trail_n + popc64(wm & lanemask_lt(w.lane));
         asg_set<LV>(w, sh, L, q);
-        *(MsVarHead*)&VREC[v] = MsVarHead{w.n_levels, reason, (uint32_t)(q & 1)};
+        level_mark<LV>(w, v);
+        VREC[v] = var_rec(w.n_levels, reason, start, size, q);
         WKA(int32_t, trail)[t] = q;
         w.ring[t & (MS_LDS_RING - 1)] = q;
     }
@@ -240,12 +256,13 @@ DEV void assign_winners(Wk& w, const MsShared& sh, const MsLayout& L, bool won, 
 
 // One candidate per lane (later chunks of a list).  `lost`: my implication is already falsified.
 template <bool LV>
-DEV void commit_implications(Wk& w, const MsShared& sh, const MsLayout& L, bool want, int q, int reason, bool& lost) {
+DEV void commit_implications(Wk& w, const MsShared& sh, const MsLayout& L, bool want, int q, int reason, bool& lost, uint32_t start = 0,
+                             uint32_t size = 0) {
     lost = false;
     const u64 m = ballot(want);
     if (m == 0) return;
     if ((m & (m - 1)) == 0) {  // single implication: no arbitration needed
-        assign_winners<LV>(w, sh, L, want, q, reason);
+        assign_winners<LV>(w, sh, L, want, q, reason, start, size);
         lds_fence();
         return;
     }
@@ -253,7 +270,7 @@ DEV void commit_implications(Wk& w, const MsShared& sh, const MsLayout& L, bool 
     const int c = claim_insert(w, want, q);
     lds_fence();
     lost = c == CLAIM_LOST;
-    assign_winners<LV>(w, sh, L, c == CLAIM_WON, q, reason);
+    assign_winners<LV>(w, sh, L, c == CLAIM_WON, q, reason, start, size);
     lds_fence();
 }
 
@@ -495,7 +512,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
             lds_fence();
             assign_winners<LV>(w, sh, L, cb == CLAIM_WON, q0, MS_REASON_BIN(fl));
             assign_winners<LV>(w, sh, L, ct == CLAIM_WON, imp_t, MS_REASON_TERN(t0 + sl));
-            assign_winners<LV>(w, sh, L, cl3 == CLAIM_WON, R0.imp, wt0.x);
+            assign_winners<LV>(w, sh, L, cl3 == CLAIM_WON, R0.imp, wt0.x, (uint32_t)wt0.z, (uint32_t)wt0.w);
             lds_fence();
             const bool xb = cf_b || cb == CLAIM_LOST, xt = cf_t || ct == CLAIM_LOST, xl = R0.cf || cl3 == CLAIM_LOST;
             const u64 cm = ballot(xb || xt || xl);
@@ -506,8 +523,9 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 w.confl_kind = kind;
                 w.confl_cref = bcast(wt0.x, f);
                 w.confl_a = bcast(fl, f);
-                w.confl_b = bcast(kind == 2 ? q0 : pr0.x, f);
-                w.confl_c = bcast(pr0.y, f);
+                // (kind 1: the clause's literal range instead of the unused literals b, c)
+                w.confl_b = bcast(kind == 2 ? q0 : (kind == 1 ? wt0.z : pr0.x), f);
+                w.confl_c = bcast(kind == 1 ? wt0.w : pr0.y, f);
             }
         }
         {   // in-place compaction of the first chunk of each group's watch list
@@ -608,12 +626,14 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 done_l = min(n_l, i0 + MS_WAVE);
                 if (ballot(R.deferred)) defer_g = min(defer_g, gl);
                 repair_overflow(w, sh, L);
-                commit_implications<LV>(w, sh, L, R.want, R.imp, wt.x, lost);
+                commit_implications<LV>(w, sh, L, R.want, R.imp, wt.x, lost, (uint32_t)wt.z, (uint32_t)wt.w);
                 const u64 cm = ballot(R.cf || lost);
                 if (cm) {
                     any_cf = true;
                     w.confl_kind = 1;
                     w.confl_cref = bcast(wt.x, first_lane(cm));
+                    w.confl_b = bcast(wt.z, first_lane(cm));
+                    w.confl_c = bcast(wt.w, first_lane(cm));
                 }
             }
             if (g == gl) { j = j_l; done = done_l; }
@@ -639,6 +659,31 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
 }
 
 // ---- backtracking --------------------------------------------------------
+// (LV) The bitmap of the variables assigned at the current decision level, from the trail: after a backjump the
+// level we land on already has literals.  One coalesced pass over that level's segment.
+DEV void cur_level_rebuild(Wk& w, const MsShared& sh, const MsLayout& L) {
+    for (uint32_t i = (uint32_t)w.lane; i < ((sh.n_vars + 31) >> 5); i += MS_WAVE) w.lcur[i] = 0;
+    lds_fence();
+    if (w.n_levels > 0) {
+        const int from = uni(WK_PTR(int32_t, w, L, trail_lim)[w.n_levels - 1]);
+        for (int i = from + w.lane; i < w.trail_n; i += MS_WAVE) {
+            const int v = WKA(int32_t, trail)[i] >> 1;
+            atomicOr((uint32_t*)&w.lcur[v >> 5], 1u << (v & 31));
+        }
+        lds_fence();
+    }
+}
+DEV void level_zero_rebuild(Wk& w, const MsShared& sh, const MsLayout& L) {
+    for (uint32_t i = (uint32_t)w.lane; i < ((sh.n_vars + 31) >> 5); i += MS_WAVE) w.lzero[i] = 0;
+    lds_fence();
+    const int to = w.n_levels > 0 ? uni(WK_PTR(int32_t, w, L, trail_lim)[0]) : w.trail_n;
+    for (int i = w.lane; i < to; i += MS_WAVE) {
+        const int v = WKA(int32_t, trail)[i] >> 1;
+        atomicOr((uint32_t*)&w.lzero[v >> 5], 1u << (v & 31));
+    }
+    lds_fence();
+}
+
 template <bool LV>
 DEV void cancel_until(Wk& w, const MsShared& sh, const MsLayout& L, int lvl) {
     if (w.n_levels <= lvl) return;
@@ -657,11 +702,17 @@ DEV void cancel_until(Wk& w, const MsShared& sh, const MsLayout& L, int lvl) {
     w.n_levels = lvl;
     if (w.ring_lo > lim) w.ring_lo = lim;
     lds_fence();
+    if (LV) cur_level_rebuild(w, sh, L);
 }
 
+template <bool LV>
 DEV void new_decision_level(Wk& w, const MsShared& sh, const MsLayout& L) {
     if (w.lane == 0) WK_PTR(int32_t, w, L, trail_lim)[w.n_levels] = w.trail_n;
     w.n_levels++;
+    if (LV) {   // nothing is assigned at the new level yet
+        for (uint32_t i = (uint32_t)w.lane; i < ((sh.n_vars + 31) >> 5); i += MS_WAVE) w.lcur[i] = 0;
+        lds_fence();
+    }
 }
 
 // ---- decision queue (move-to-front as an append-only array) ---------------
@@ -670,19 +721,18 @@ DEV void new_decision_level(Wk& w, const MsShared& sh, const MsLayout& L) {
 // it is assigned.
 DEV void vm_compact(Wk& w, const MsShared& sh, const MsLayout& L) {
     int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
-    MsVarRec* vrec = VREC;
     int j = 0;
     for (int i0 = 0; i0 < w.vm_end; i0 += MS_WAVE) {
         int i = i0 + w.lane;
         int v = -1;
         bool live = false;
-        if (i < w.vm_end) { v = vm_order[i]; live = vrec[v].vm_pos == i; }
+        if (i < w.vm_end) { v = vm_order[i]; live = VMPOS[v] == i; }
         u64 m = ballot(live);
         wave_fence();
         if (live) {
             int d = j + popc64(m & lanemask_lt(w.lane));
             vm_order[d] = v;
-            vrec[v].vm_pos = d;
+            VMPOS[v] = d;
         }
         j += popc64(m);
         wave_fence();
@@ -694,7 +744,6 @@ DEV void vm_compact(Wk& w, const MsShared& sh, const MsLayout& L) {
 template <bool LV>
 DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
     const int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
-    const MsVarRec* vrec = VREC;
     // Every candidate costs two random lines (its record for the liveness check, its assignment word).  The next
     // unassigned variable is usually among the first few entries (the search position follows the queue front),
     // so the first probe looks at 16 candidates only and only a miss widens to the whole wave.
@@ -706,7 +755,7 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
         bool ok = false;
         if (w.lane < width && idx >= 0) {
             v = vm_order[idx];
-            ok = vrec[v].vm_pos == idx && lit_value<LV>(w, sh, L, 2 * v) == MS_VAL_UNDEF;
+            ok = VMPOS[v] == idx && lit_value<LV>(w, sh, L, 2 * v) == MS_VAL_UNDEF;
         }
         u64 m = ballot(ok);
         if (m) {
@@ -727,9 +776,15 @@ DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, MsVarRec* v
                        int& path_c, int& n_out, int& n_clear) {
     int v = q >> 1;
     bool fresh = false, cur = false;
-    if (act && !(LV && seen_get<LV>(w, sh, L, v))) {
+    if (LV) {   // everything analysis asks about a literal is a bit in LDS: marked? level 0? current level?
+        if (act) {
+            const uint32_t bit = 1u << (v & 31);
+            fresh = !(w.lseen[v >> 5] & bit) && !(w.lzero[v >> 5] & bit);
+            cur = fresh && (w.lcur[v >> 5] & bit);
+        }
+    } else if (act) {
         const MsVarRec vr = vrec[v];
-        fresh = (LV || !vr.seen) && vr.level > 0;
+        fresh = !vr.seen && vr.level > 0;
         cur = fresh && vr.level >= dl;
     }
     u64 fm = ballot(fresh), cm = ballot(cur);
@@ -758,8 +813,9 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     for (;;) {
         if (kind == 1) {
             const int32_t* cl;
-            int size;
-            clause_range(w, sh, L, cref, cl, size);
+            int size = bc;     // kind 1: (bb, bc) = the clause's literal range when known (size 0: look it up)
+            if (size > 0) cl = ((uint32_t)cref < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + (uint32_t)bb;
+            else clause_range(w, sh, L, cref, cl, size);
             if ((uint32_t)cref >= sh.n_orig && w.lane == 0) lc_lbd[cref - sh.n_orig] |= 0x80000000u;  // used
             for (int k0 = 0; k0 < size; k0 += MS_WAVE) {
                 int k = k0 + w.lane;
@@ -815,13 +871,14 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
         }
         index--;
         const int v = p >> 1;
-        const int r = uni(VREC[v].reason);
+        const MsVarRec pr = VREC[v];       // reason and, for a long reason, where its literals are: one round trip
+        const int r = uni(pr.reason);
         wave_fence();
         if (w.lane == 0) seen_clr<LV>(w, sh, L, v);
         lds_fence();
         path_c--;
         if (path_c <= 0) break;
-        if (r >= 0) { kind = 1; cref = r; }
+        if (r >= 0) { kind = 1; cref = r; bb = uni((int)pr.start); bc = uni((int)pr.size); }
         else if (MS_IS_TERN_REASON(r)) {
             const int e = MS_TERN_REASON_ENTRY(r);
             const int2 pr = ((const int2*)sh.tern_pairs)[e];
@@ -843,12 +900,19 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
         int q = act ? learnt_buf[i] : 0;
         if (act) {
             const int qv = q >> 1;
-            int r = VREC[qv].reason;
-            auto implied = [&](int l) { return (l >> 1) == qv || seen_get<LV>(w, sh, L, l >> 1) || VREC[l >> 1].level == 0; };
+            const MsVarRec qr = VREC[qv];
+            const int r = qr.reason;
+            auto implied = [&](int l) {
+                const int lv = l >> 1;
+                if (lv == qv) return true;
+                if (LV) return ((w.lseen[lv >> 5] | w.lzero[lv >> 5]) >> (lv & 31) & 1u) != 0;
+                return seen_get<LV>(w, sh, L, lv) || VREC[lv].level == 0;
+            };
             if (r >= 0) {
                 const int32_t* cl;
-                int size;
-                clause_range(w, sh, L, r, cl, size);
+                int size = (int)qr.size;
+                if (size > 0) cl = ((uint32_t)r < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + qr.start;
+                else clause_range(w, sh, L, r, cl, size);
                 bool red = true;
                 for (int k = 0; k < size && red; k += 4) {
                     const int4 q4 = *(const int4*)(cl + k);
@@ -925,7 +989,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
             int v = toclear[i];
             seen_clr<LV>(w, sh, L, v);
             vm_order[w.vm_end + i] = v;
-            vrec[v].vm_pos = w.vm_end + i;
+            VMPOS[v] = w.vm_end + i;
         }
         w.vm_end += n_clear;
     }
@@ -1086,7 +1150,11 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
     for (int i = w.lane; i < w.trail_n; i += MS_WAVE) {
         int v = WKA(int32_t, trail)[i] >> 1;
         int r = VREC[v].reason;
-        if (r >= 0 && (uint32_t)r >= sh.n_orig) VREC[v].reason = (int)(sh.n_orig + remap[(uint32_t)r - sh.n_orig]);
+        if (r >= 0 && (uint32_t)r >= sh.n_orig) {
+            const uint32_t nk2 = remap[(uint32_t)r - sh.n_orig];
+            VREC[v].reason = (int)(sh.n_orig + nk2);
+            VREC[v].start = lrec[nk2].start;     // (the reduction moved the literals of kept clauses)
+        }
     }
     wave_fence();
 }
@@ -1291,7 +1359,8 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     } else {
         int cref = add_learnt<LV>(w, sh, L, lr.n, lr.lbd);
         if (cref < 0) return false;
-        enqueue_uniform<LV>(w, sh, L, uni(learnt_buf[0]), cref);
+        const MsClauseHdr lh = clause_hdr_of(w, sh, L, cref);
+        enqueue_uniform<LV>(w, sh, L, uni(learnt_buf[0]), cref, (uint32_t)uni((int)lh.start), (uint32_t)uni((int)lh.size));
     }
     PROF_MARK(PF_BACKJUMP);
     ls.learnt_total++;
@@ -1344,7 +1413,7 @@ DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     while (w.n_levels < ls.n_assumps) {
         int a = uni(assumps[w.n_levels]);
         int va = lit_value<LV>(w, sh, L, a);
-        if (va == MS_VAL_TRUE) new_decision_level(w, sh, L);      // dummy level
+        if (va == MS_VAL_TRUE) new_decision_level<LV>(w, sh, L);      // dummy level
         else if (va == MS_VAL_FALSE) { w.status = MS_ST_REFUTED; return; }   // the cube is refuted
         else { next = a; break; }
     }
@@ -1354,7 +1423,7 @@ DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         w.c_dec++;
         next = uni(2 * v + (int)VREC[v].phase);
     }
-    new_decision_level(w, sh, L);
+    new_decision_level<LV>(w, sh, L);
     enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);
     PROF_MARK(PF_DECIDE);
 }
@@ -1386,11 +1455,14 @@ __global__ __launch_bounds__(MS_WAVE, ONE ? 1 : MS_SEARCH_WAVES_PER_SIMD) void m
     Wk w;
     w.lane = (int)threadIdx.x;
     w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
-    w.lseen = s_lval + ((sh.n_vars + 15) >> 4);   // (LV) analysis marks behind the assignment words
+    w.lseen = s_lval + ((sh.n_vars + 15) >> 4);   // (LV) three bitmaps behind the assignment words
+    w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);
+    w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
     if (w.lane == 0) s_ov = 0;
     if (LV) for (uint32_t i = (uint32_t)w.lane; i < ((sh.n_vars + 31) >> 5); i += MS_WAVE) w.lseen[i] = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     wk_uniformize(w);
+    if (LV) { level_zero_rebuild(w, sh, L); cur_level_rebuild(w, sh, L); }
     MsState* st = WKA(MsState, state);
     if (w.lane < MS_LBDQ) s_lbdq[w.lane] = st->lbdq[w.lane];
     lds_fence();
@@ -1458,7 +1530,7 @@ __global__ __launch_bounds__(MS_WAVE, ONE ? 1 : MS_SEARCH_WAVES_PER_SIMD) void m
                 if (v < 0) { w.status = MS_ST_SAT; break; }
                 w.c_dec++;
                 const int next = uni(2 * v + (int)VREC[v].phase);
-                new_decision_level(w, sh, L);
+                new_decision_level<LV>(w, sh, L);
                 enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);
                 PROF_MARK(PF_DECIDE);
             }
@@ -1506,10 +1578,13 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     Wk w;
     w.lane = (int)threadIdx.x;
     w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
-    w.lseen = s_lval;   // (no analysis in this kernel)
+    w.lseen = s_lval + ((sh.n_vars + 15) >> 4);   // (no analysis in this kernel; the level bitmaps are still maintained)
+    w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);
+    w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
     if (w.lane == 0) s_ov = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     wk_uniformize(w);
+    if (LV) { level_zero_rebuild(w, sh, L); cur_level_rebuild(w, sh, L); }
     lds_fence();
     const u64 t0 = __builtin_readcyclecounter();
     const int n_script = WKA(MsState, state)->n_script;
@@ -1520,7 +1595,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
         int va = lit_value<LV>(w, sh, L, a);
         if (va == MS_VAL_TRUE) continue;
         if (va == MS_VAL_FALSE) { confl = true; break; }
-        new_decision_level(w, sh, L);
+        new_decision_level<LV>(w, sh, L);
         enqueue_uniform<LV>(w, sh, L, a, MS_REASON_NONE);
         confl = propagate<LV>(w, sh, L);
     }
@@ -1553,10 +1628,13 @@ __global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout
     Wk w;
     w.lane = (int)threadIdx.x;
     w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
-    w.lseen = s_lval;
+    w.lseen = s_lval + ((sh.n_vars + 15) >> 4);
+    w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);
+    w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
     if (w.lane == 0) s_ov = 0;
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     wk_uniformize(w);
+    if (LV) { level_zero_rebuild(w, sh, L); cur_level_rebuild(w, sh, L); }
     lds_fence();
     const u64 t0 = __builtin_readcyclecounter();
     const int n_script = WKA(MsState, state)->n_script;
@@ -1573,7 +1651,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout
         bool ran = false;
         if (lit_value<LV>(w, sh, L, a) == MS_VAL_UNDEF) {
             const int base = w.trail_n;
-            new_decision_level(w, sh, L);
+            new_decision_level<LV>(w, sh, L);
             enqueue_uniform<LV>(w, sh, L, a, MS_REASON_NONE);
             const bool failed = propagate<LV>(w, sh, L);
             res = failed ? -1 : w.trail_n - base - 1;

@@ -73,13 +73,13 @@ struct MsLitHdr { uint32_t bin_off, bin_n, tern_off, tern_n; };
 // immutable binary / ternary list header, so that a dequeued literal costs ONE 32-byte access to one line
 // instead of a private and a shared one (+16 B x 2 x n_vars per worker: 3 MB of 37 at rect 64x64).
 struct MsWatchHdr { uint32_t base, size, cap, pad; uint32_t bin_off, bin_n, tern_off, tern_n; };
-// Per-variable record: everything BCP, backtracking and analysis touch for one variable sits in ONE
-// 16-byte slot (one 64-byte line per assignment instead of five).
-// mstamp: memo of clause minimisation, (conflict number & 0x3fff) << 2 | state (2 = implied by the clause, 3 = not)
-// The first 12 bytes are written by ONE store when the variable is assigned (phase = its polarity now, which is
-// what phase saving would record at unassignment; seen and mstamp are 0 then), so backtracking writes nothing here.
-struct MsVarRec { int32_t level, reason; uint8_t phase, seen; uint16_t mstamp; int32_t vm_pos; };
-struct MsVarHead { int32_t level, reason; uint32_t phase_seen_mstamp; };
+// Per-variable record: everything backtracking and analysis need to know about an assigned variable sits in ONE
+// 16-byte slot, written by ONE store when the variable is assigned: its level, its reason and - for a long / learnt
+// reason - where that clause's literals are (start, size; size 0 = look the clause record up), so that conflict
+// analysis goes from a literal to its reason's literals in one dependent round trip.  phase = its polarity now, which
+// is what phase saving would record at unassignment, so backtracking writes nothing here.  seen: analysis mark of
+// the builds that keep the assignment in HBM (the LDS builds keep a bitmap).
+struct MsVarRec { int32_t level, reason; uint32_t start; uint16_t size; uint8_t phase, seen; };
 // Long / learnt clause header: literals start 16-byte aligned (4 literals) so that a lane reads 4 at a time.
 struct MsClauseHdr { uint32_t start, size; };
 // Per worker and clause (original long clauses first, then learnt ones): the two watched literals AND where the
@@ -102,7 +102,8 @@ struct MsLayout {
     uint64_t state;       // MsState
     uint64_t val;         // uint32 [(n_vars+15)/16]  assignment, 2 bits per variable (MS_ASG_*): the whole
                           //        assignment of a worker is 24 KB at 64x64, so all workers' fit in L2 + Infinity Cache
-    uint64_t vrec;        // MsVarRec [n_vars]  level, reason, decision-queue position, saved phase, seen mark
+    uint64_t vrec;        // MsVarRec [n_vars]  level, reason (+ its literal range), saved phase, seen mark
+    uint64_t vm_pos;      // int32  [n_vars]  position of the variable's live entry in vm_order
     uint64_t trail;       // int32  [n_vars]
     uint64_t trail_lim;   // int32  [n_vars+1]
     uint64_t vm_order;    // int32  [vm_cap]   move-to-front queue as an append-only array

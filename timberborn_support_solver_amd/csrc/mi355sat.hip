@@ -93,7 +93,7 @@ __global__ void ms_customize_kernel(MsLayout L, char* slabs, uint32_t n_workers,
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
             uint32_t v = (uint32_t)(((uint64_t)a * i + b) % n);
             order[i] = (int32_t)v;
-            vrec[v].vm_pos = (int32_t)i;
+            ((int32_t*)(slab + L.vm_pos))[v] = (int32_t)i;
             if (pm == 1) vrec[v].phase = 0;
             else if (pm == 2) vrec[v].phase = (uint8_t)((((uint64_t)v * 0x9E3779B97F4A7C15ull + z) >> 40) & 1);
         }
@@ -662,6 +662,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     place(L.state, sizeof(MsState));
     place(L.val, 4 * (((size_t)nv + 15) / 16));
     place(L.vrec, sizeof(MsVarRec) * (size_t)nv);
+    place(L.vm_pos, 4 * (size_t)nv);
     place(L.trail, 4 * (size_t)nv);
     place(L.trail_lim, 4 * ((size_t)nv + 1));
     place(L.vm_order, 4 * (size_t)L.vm_cap);
@@ -700,7 +701,8 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     int32_t* vm_order = (int32_t*)(T + L.vm_order);
     for (uint32_t e = 0; e < nv; e++) {   // initial decision order: the caller's numbering, highest first
         const uint32_t v = P.perm[e];
-        vrec[v] = MsVarRec{0, MS_REASON_NONE, /*phase=*/1, /*seen=*/0, /*mstamp=*/0, (int32_t)(nv - 1 - e)};
+        vrec[v] = MsVarRec{0, MS_REASON_NONE, 0, 0, /*phase=*/1, /*seen=*/0};
+        ((int32_t*)(T + L.vm_pos))[v] = (int32_t)(nv - 1 - e);
         vm_order[nv - 1 - e] = (int32_t)v;
     }
     int32_t* trail = (int32_t*)(T + L.trail);
@@ -743,7 +745,7 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.sh.tern_owner = s.d_tern_owner.p;
     // assignment in LDS (2 bits per variable) when it still leaves room for 12 waves per CU
     // (measured on rect 64x64: 12 waves/CU with the assignment in HBM beat 6 waves/CU with it in LDS)
-    s.lds_val_bytes = ((P.n_vars + 15) / 16) * 4 + ((P.n_vars + 31) / 32) * 4;   // 2-bit assignment + 1-bit analysis marks
+    s.lds_val_bytes = ((P.n_vars + 15) / 16) * 4 + 3 * ((P.n_vars + 31) / 32) * 4;   // 2-bit assignment + three 1-bit maps (marks, current level, level 0)
     s.lds_val = s.opts.lds_val == 1 || (s.opts.lds_val == 0 && s.lds_val_bytes <= 10 * 1024);
     if (s.lds_val_bytes > 150 * 1024) s.lds_val = false;
     // worker count limited by free HBM
