@@ -297,7 +297,7 @@ def main():
             "config": {"workload": f"rect {n} {n} k-sweep at the first-UNSAT bound: at-most-k for k={args.k_hi}..{args.k_lo}, "
                                    f"{args.platforms} platforms, one totalizer CNF shared by all k",
                        "vars": int(cnf.n_vars), "clauses": int(cnf.n_clauses), "literals": int(len(cnf.lits)),
-                       "workers_per_gpu": workers, "instances_per_gpu": len(ks), "slice_ms": args.slice_ms,
+                       "workers_per_gpu": int(st1["workers"]), "instances_per_gpu": len(ks), "slice_ms": args.slice_ms,
                        "exchange": ("off" if args.share < 0 else "on") + " in the throughput sweep (value); on in the first-UNSAT line",
                        "parallelism": f"{world} GPU(s) x {workers} wavefront workers; value: seeds sharded over ranks (weak); "
                                       f"first_unsat_sharded: bounds k = k_hi - rank - i*{world} of one ladder sharded (strong)"},

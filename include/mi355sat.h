@@ -127,6 +127,8 @@ typedef struct mi355sat_stats_t {
     uint64_t simp_units;           /* simplification before search: failed literals + necessary assignments found by probing */
     uint64_t simp_equivalences;    /* variables replaced by an equivalent literal */
     uint64_t simp_clauses_removed; /* clauses subsumed or strengthened */
+    uint64_t workers;              /* search workers (wavefronts) of the last solve / batch / sweep: what was asked for, or
+                                      what device memory had room for */
 } mi355sat_stats_t;
 
 /* --- lifecycle (Default::default / Drop) --------------------------------- */

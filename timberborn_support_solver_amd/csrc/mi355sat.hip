@@ -636,24 +636,25 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     // capacities
     const uint64_t base_lits = P.cl_lits.size() + 3 * P.tern_pairs.size() / 3;
     L.learnt_cap = (uint32_t)std::min<uint64_t>(1u << 17, std::max<uint64_t>(1u << 15, 2 * (uint64_t)no + 4096));
-    L.learnt_lit_cap = (uint32_t)std::min<uint64_t>(4u << 20, std::max<uint64_t>(1u << 20, 8 * base_lits));
+    // (round 2: 2 M literals at most instead of 4 M - a store that runs full reduces early, add_learnt / on_conflict)
+    L.learnt_lit_cap = (uint32_t)std::min<uint64_t>(2u << 20, std::max<uint64_t>(1u << 19, 6 * base_lits));
     L.vm_cap = 3 * nv + 256;
     L.assump_cap = assump_cap;
     L.script_cap = script_cap;
     // watch lists: literal t's list holds the clauses currently watching ~t.  Initial slots get
-    // 50% + 4 entries of slack; a list that outgrows its slot moves to the top of the bump pool and
+    // 50% + 2 entries of slack; a list that outgrows its slot moves to the top of the bump pool and
     // the device compacts the pool again at every learnt-clause reduction (rebuild_watches).
     std::vector<uint32_t> cap(2 * (size_t)nv, 0);
     for (uint32_t c = 0; c < no; c++) { cap[P.cl_lits[P.cl_hdr[c].start] ^ 1]++; cap[P.cl_lits[P.cl_hdr[c].start + 1] ^ 1]++; }
     uint64_t pool_need = 0;
     std::vector<uint32_t> base(2 * (size_t)nv);
     for (size_t t = 0; t < cap.size(); t++) {
-        cap[t] += (cap[t] >> 1) + 4;
+        cap[t] += (cap[t] >> 1) + 2;
         base[t] = (uint32_t)pool_need;
         pool_need += cap[t];
     }
     // room for a dense rebuild with every learnt slot in use, plus 50% for relocations in between
-    uint64_t dense_max = 3 * ((uint64_t)no + L.learnt_cap) + 8 * (uint64_t)nv;
+    uint64_t dense_max = 3 * ((uint64_t)no + L.learnt_cap) + 4 * (uint64_t)nv;   // (rebuild_watches: size + size/2 + 2 per list)
     uint64_t pool_cap = dense_max + dense_max / 2 + (1u << 16);
     if (pool_cap > 0xfffffff0ull) throw HipErr{"formula too large (watch pool)"};
     L.pool_cap = (uint32_t)pool_cap;
@@ -1379,6 +1380,7 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     customize(s, &a_int, &assump_off, nullptr, nullptr, n_instances, sw.split ? (int32_t)n_instances : -1);
     HIPCHK(hipStreamSynchronize(s.stream));
     const uint32_t W = s.n_workers;
+    s.stats.workers = W;
     sw.base_assump = a_int;
     sw.base_off = assump_off;
     sw.w_inst.assign(W, 0);

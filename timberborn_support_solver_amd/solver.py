@@ -52,7 +52,8 @@ class Mi355SatStats(ctypes.Structure):
                 ("n_deq", "n_watch", "n_cl_lit", "n_move", "n_enq", "n_sat", "n_unsat", "n_terminated",
                  "bcp_steps", "bcp_requeued")] + \
                [("shared_exported", ctypes.c_uint64), ("shared_imported", ctypes.c_uint64), ("shared_imported_units", ctypes.c_uint64),
-                ("simp_units", ctypes.c_uint64), ("simp_equivalences", ctypes.c_uint64), ("simp_clauses_removed", ctypes.c_uint64)]
+                ("simp_units", ctypes.c_uint64), ("simp_equivalences", ctypes.c_uint64), ("simp_clauses_removed", ctypes.c_uint64),
+                ("workers", ctypes.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
