@@ -177,6 +177,11 @@ int mi355sat_sweep_step(mi355sat* s, int32_t* results /* may be NULL */, uint64_
  * SAT one and every k below an UNSAT one is implied).  Their result stays 0, they count as decided, and
  * their workers move to the instances still open - as do the workers of every instance that gets its verdict. */
 int mi355sat_sweep_drop(mi355sat* s, const uint64_t* instances, uint64_t n);
+/* Priorities: open instance i gets about weights[i] / sum(weights of open instances) of the workers from the next
+ * step on (workers move between open instances if need be; they keep their learnt clauses).  The decreasing-k loop
+ * concentrates the fleet on the two bounds that decide it: the highest open one (a model there lowers the ceiling)
+ * and the lowest open one (a refutation there raises the floor).  n must be the number of instances. */
+int mi355sat_sweep_set_weights(mi355sat* s, const double* weights, uint64_t n);
 /* Take withdrawn, still undecided instances up again: idle workers (parked, or of decided / withdrawn instances)
  * move to them.  The sharded sweep (one process per GPU) begins every rank with all bounds, withdraws
  * the other ranks' shards, and reopens the bounds still open anywhere once its own shard is decided. */

@@ -132,6 +132,17 @@ std::vector<LoopIteration> solver_loop_sweep(const WorldGrid& world, const Encod
         for (size_t i = 0; i < ks.size(); i++)
             if (res[i] == 0 && ((best_c >= 0 && (long)ks[i] >= best_c) || (long)ks[i] < unsat_k)) drop.push_back(i);
         if (!drop.empty() && mi355sat_sweep_drop(s, drop.data(), drop.size()) < 0) fail("sweep_drop");
+        // the two open bounds that decide the loop - the highest (a model there lowers the ceiling) and the lowest (a
+        // refutation there raises the floor) - share the fleet; the ones in between keep a few workers each
+        long hi = -1, lo = -1;
+        for (size_t i = 0; i < ks.size(); i++)
+            if (res[i] == 0 && (best_c < 0 || (long)ks[i] < best_c) && (long)ks[i] > unsat_k) {
+                if (hi < 0 || (long)ks[i] > hi) hi = (long)ks[i];
+                if (lo < 0 || (long)ks[i] < lo) lo = (long)ks[i];
+            }
+        std::vector<double> weights(ks.size(), 0.02);
+        for (size_t i = 0; i < ks.size(); i++) if ((long)ks[i] == hi || (long)ks[i] == lo) weights[i] = 1.0;
+        if (mi355sat_sweep_set_weights(s, weights.data(), weights.size()) < 0) fail("sweep_set_weights");
     }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     mi355sat_sweep_end(s);

@@ -1288,6 +1288,8 @@ struct Sweep {
     uint32_t n_instances = 0;
     std::vector<int32_t> results, winner;
     std::vector<uint8_t> dropped;                // withdrawn by the caller: result stays INTERRUPTED, counts as decided
+    std::vector<double> weights;                 // share of the fleet each open instance should get (empty: equal)
+    bool weights_dirty = false;
     std::vector<int32_t> base_assump;            // internal literals
     std::vector<uint64_t> base_off;
     uint64_t n_moved = 0;
@@ -1488,9 +1490,34 @@ void rebalance_workers(mi355sat& s, Sweep& sw) {
     if (open.empty() || s.opts.rebalance < 0) {
         for (uint32_t w : movable) park(w);
     } else {
+        // Each open instance's share of the fleet follows its weight (mi355sat_sweep_set_weights; default equal).
+        // Workers of instances well above their share (> 25 % and > 2 workers) are taken off them too - highest
+        // worker index first, never the last one - so that a caller's change of priorities takes effect.
+        double wsum = 0;
+        for (uint32_t i : open) wsum += sw.weights.empty() ? 1.0 : std::max(1e-6, sw.weights[i]);
+        uint32_t total = (uint32_t)movable.size();
+        for (uint32_t i : open) total += cnt[i];
+        std::vector<double> target(n_instances, 0);
+        for (uint32_t i : open) target[i] = std::max(1.0, total * (sw.weights.empty() ? 1.0 : std::max(1e-6, sw.weights[i])) / wsum);
+        if (!sw.weights.empty()) {
+            std::vector<uint32_t> surplus(n_instances, 0);
+            for (uint32_t i : open)
+                if (cnt[i] > target[i] * 1.25 + 2) surplus[i] = cnt[i] - (uint32_t)target[i];
+            for (uint32_t w = s.n_alloc; w-- > 0;) {
+                const uint32_t inst = (uint32_t)sw.w_inst[w];
+                if (!inst_open(sw, inst) || !surplus[inst] || sw.sts[w].status != MS_ST_RUNNING || cnt[inst] <= 1) continue;
+                surplus[inst]--;
+                cnt[inst]--;
+                movable.push_back(w);
+            }
+        }
         for (uint32_t w : movable) {
             uint32_t best = open[0];
-            for (uint32_t i : open) if (cnt[i] < cnt[best]) best = i;
+            double best_need = -1e30;
+            for (uint32_t i : open) {   // the instance furthest below its share, relative to it
+                const double need = (target[i] - cnt[i]) / target[i];
+                if (need > best_need) { best_need = need; best = i; }
+            }
             cnt[best]++;
             sw.w_inst[w] = (int32_t)best;
             sw.w_busy[w] = 1;
@@ -1572,7 +1599,8 @@ int sweep_step(mi355sat& s, Sweep& sw) {
     HIPCHK(hipMemsetAsync(s.d_any_done.p, 0, sizeof(int32_t), s.stream));
     if (sw.decided == n_instances || (sw.stop_at_first && sw.decided > 0)) return 0;
     if (sw.split) schedule_cubes(s, sw);
-    else if (n_instances > 1 && sw.decided > 0) rebalance_workers(s, sw);
+    else if (n_instances > 1 && (sw.decided > 0 || sw.weights_dirty)) rebalance_workers(s, sw);
+    sw.weights_dirty = false;
     return 0;
 }
 
@@ -1947,6 +1975,16 @@ int mi355sat_sweep_drop(mi355sat* s, const uint64_t* instances, uint64_t n) {
         return 0;
     } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
     catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
+}
+
+int mi355sat_sweep_set_weights(mi355sat* s, const double* weights, uint64_t n) {
+    if (!s || !s->sweep || !weights) return MI355SAT_ERR_STATE;
+    Sweep& sw = s->sweep->sw;
+    if (n != sw.n_instances) { s->err = "one weight per instance"; return MI355SAT_ERR_ARG; }
+    std::vector<double> w(weights, weights + n);
+    for (double x : w) if (!(x >= 0)) { s->err = "weights must be >= 0"; return MI355SAT_ERR_ARG; }
+    if (w != sw.weights) { sw.weights.swap(w); sw.weights_dirty = true; }
+    return 0;
 }
 
 int mi355sat_sweep_reopen(mi355sat* s, const uint64_t* instances, uint64_t n) {

@@ -84,6 +84,16 @@ def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_in
     return first + _sweep_below(grid, encoding, first[-1]["count"] - 1, make_solver, out, on_interrupter, time_limit)
 
 
+def frontier_weights(ks, res, best_c, unsat_k, rest=0.02):
+    """The refinement ends when max UNSAT k + 1 == min SAT count, so two open bounds decide it: the highest (a
+    model there lowers the ceiling - the reference's own next iteration, main.rs:346) and the lowest (a refutation
+    there raises the floor).  They share the fleet; the bounds in between keep a few workers each (their learnt
+    clauses travel through the exchange either way)."""
+    open_ks = [k for k, r in zip(ks, res) if r == SolverResult.Interrupted and (best_c is None or k < best_c) and k > unsat_k]
+    hi, lo = (max(open_ks), min(open_ks)) if open_ks else (None, None)
+    return [1.0 if k in (hi, lo) else rest for k in ks]
+
+
 def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limit):
     cnf = encoding.with_limits_into_cnf(PlatformLimits({(1, 1): k0}), sweep=True)
     ks = list(range(k0, -1, -1))
@@ -124,6 +134,7 @@ def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limi
             break
         solver.sweep_drop([i for i, k in enumerate(ks) if res[i] == SolverResult.Interrupted and
                            ((best_c is not None and k >= best_c) or k < unsat_k)])
+        solver.sweep_set_weights(frontier_weights(ks, res, best_c, unsat_k))
     dt = time.perf_counter() - t0
     layout = None
     if best_i is not None:

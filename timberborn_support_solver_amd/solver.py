@@ -88,6 +88,7 @@ def _bind(L):
     L.mi355sat_sweep_end.argtypes = [vp]
     L.mi355sat_sweep_drop.argtypes = [vp, vp, ctypes.c_uint64]
     L.mi355sat_sweep_reopen.argtypes = [vp, vp, ctypes.c_uint64]
+    L.mi355sat_sweep_set_weights.argtypes = [vp, vp, ctypes.c_uint64]
     L.mi355sat_sweep_model_of.argtypes = [vp, ctypes.c_uint64, vp, ctypes.c_uint64]
     L.mi355sat_propagate_batch.argtypes = [vp, vp, vp, ctypes.c_uint64, vp, ctypes.c_uint64, vp, vp, ctypes.c_int32]
     L.mi355sat_val.argtypes = [vp, ctypes.c_int32]
@@ -212,6 +213,11 @@ class Mi355Sat:
         idx = np.asarray(list(instances), dtype=np.uint64)
         if len(idx):
             self._check(self._L.mi355sat_sweep_drop(self._h, _p(idx), len(idx)), "sweep_drop")
+
+    def sweep_set_weights(self, weights):
+        """Share of the fleet per instance (only the open ones count); takes effect at the next step."""
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        self._check(self._L.mi355sat_sweep_set_weights(self._h, _p(w), len(w)), "sweep_set_weights")
 
     def sweep_reopen(self, instances):
         """Take withdrawn, still undecided instances up again (idle workers move to them)."""

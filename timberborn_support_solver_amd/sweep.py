@@ -164,6 +164,9 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
         solver.sweep_drop([idx[k] for k in active - want if local[k][0] == "open"])
         solver.sweep_reopen([idx[k] for k in want - active])
         active = want
+        if active:   # within what this rank has open: the two bounds that decide the loop share its workers
+            hi, lo = max(active), min(active)
+            solver.sweep_set_weights([1.0 if k in (hi, lo) else 0.02 for k in ks])
     dt = time.perf_counter() - t0
     solver.sweep_end()
     stats = solver.stats()
