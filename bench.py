@@ -222,7 +222,7 @@ def main():
         barrier()
         tg = time.perf_counter()
         hist = solver_loop_sweep_sharded(g2, e2, PlatformLimits({(1, 1): max(4, m * m // 24)}), out=lambda line: None, time_limit=120,
-                                         make_solver=lambda: Mi355Sat(device=device_index, slice_ms=10, seed=1000 + rank),
+                                         make_solver=lambda: Mi355Sat(device=device_index, seed=1000 + rank),
                                          device=coll_dev, stats_out=st_sh)
         barrier()
         gpu_s = time.perf_counter() - tg
@@ -241,7 +241,7 @@ def main():
         from timberborn_support_solver_amd import solver_loop_sweep
         tg = time.perf_counter()
         hist = solver_loop_sweep(g2, e2, PlatformLimits({(1, 1): k0}), out=lambda line: None, time_limit=120,
-                                 make_solver=lambda: Mi355Sat(device=device_index, slice_ms=10))
+                                 make_solver=lambda: Mi355Sat(device=device_index))
         gpu_s = time.perf_counter() - tg
         sat = [h for h in hist if h["result"] == SolverResult.Sat]
         kstar = sat[-1]["count"] if sat and hist[-1]["result"] == SolverResult.Unsat and all(h["valid"] for h in sat) else None

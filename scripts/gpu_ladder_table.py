@@ -34,7 +34,7 @@ for m in sizes:
     gpu = []
     for rep in range(reps):
         t0 = time.perf_counter()
-        hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=limit, make_solver=lambda: Mi355Sat(slice_ms=10))
+        hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=limit, make_solver=lambda: Mi355Sat())
         ok = hist[-1]["result"] == SolverResult.Unsat
         gpu.append((round(time.perf_counter() - t0, 2), [h["count"] for h in hist if h["count"]][-1] if ok else None))
         print(f"rect {m}: GPU run {rep} {gpu[-1]}", flush=True)

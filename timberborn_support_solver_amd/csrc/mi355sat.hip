@@ -1154,14 +1154,14 @@ void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_
 
 struct SliceResult { float ms; };
 
-SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_refuted = true, uint32_t active = 0) {
+SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_refuted = true, uint32_t active = 0, int auto_slice_ms = 20) {
     if (active == 0 || active > s.n_alloc) active = s.n_alloc;   // workers [0, active) run this slice
     MsParams prm{};
     prm.n_workers = active;
     prm.slice_conflicts = s.opts.slice_conflicts > 0 ? (uint32_t)s.opts.slice_conflicts : 0xffffffffu;
     prm.slice_props = 0;
     // default: time-bounded slices (all workers stop together; no straggler tail), 20 ms
-    const int slice_ms = s.opts.slice_ms > 0 ? s.opts.slice_ms : (s.opts.slice_conflicts > 0 ? 0 : 20);
+    const int slice_ms = s.opts.slice_ms > 0 ? s.opts.slice_ms : (s.opts.slice_conflicts > 0 ? 0 : auto_slice_ms);
     prm.slice_ticks = slice_ms > 0 ? (uint64_t)slice_ms * 100000ull : 0;
     prm.stop_flag = s.stop_flag;
     prm.stop_on_any = stop_on_any ? 1 : 0;
@@ -1552,7 +1552,11 @@ int sweep_step(mi355sat& s, Sweep& sw) {
         active = std::min(s.n_workers, std::max(want, n_instances) / n_instances * n_instances);
     }
     if (active > s.n_alloc) grow_workers(s, n_instances, active);
-    SliceResult sr = launch_slice(s, 0, /*stop_on_any=*/n_instances == 1 || sw.stop_at_first, /*done_on_refuted=*/!sw.split, active);
+    // default slice length: 20 ms while a solve is young (easy bounds are decided within a few), 50 ms after one second
+    // and 100 ms after ten of kernel time - the host's share per slice (collecting states, the caller's loop) was a
+    // quarter of the wall-clock of the rect 26x26 ladder with 10 ms slices
+    const int auto_ms = sw.ramp_ms < 1000.f ? 20 : (sw.ramp_ms < 10000.f ? 50 : 100);
+    SliceResult sr = launch_slice(s, 0, /*stop_on_any=*/n_instances == 1 || sw.stop_at_first, /*done_on_refuted=*/!sw.split, active, auto_ms);
     sw.ramp_ms += sr.ms;
     proof_drain(s);
     gather_states(s, sw.sts);
@@ -1948,6 +1952,9 @@ int mi355sat_sweep_step(mi355sat* s, int32_t* results_out, uint64_t* n_decided) 
         s->stats = s->sweep->base;
         s->stats.kernel_seconds = keep.kernel_seconds;
         s->stats.kernel_launches = keep.kernel_launches;
+        s->stats.workers = keep.workers;
+        s->stats.simp_units = keep.simp_units; s->stats.simp_equivalences = keep.simp_equivalences;
+        s->stats.simp_clauses_removed = keep.simp_clauses_removed;
         s->stats.solve_seconds = keep.solve_seconds + (now_s() - t0);
         accumulate_stats(*s, sw.sts);
         return rc;
