@@ -36,6 +36,7 @@ for m in sizes:
         t0 = time.perf_counter()
         hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=limit, make_solver=lambda: Mi355Sat())
         ok = hist[-1]["result"] == SolverResult.Unsat
-        gpu.append((round(time.perf_counter() - t0, 2), [h["count"] for h in hist if h["count"]][-1] if ok else None))
+        gpu.append((round(time.perf_counter() - t0, 2), [h["count"] for h in hist if h["count"]][-1] if ok else None,
+                    [round(h["seconds"], 1) for h in hist[-2:]]))
         print(f"rect {m}: GPU run {rep} {gpu[-1]}", flush=True)
     print(f"rect {m} -l1:{m}: CPU {cpu_s:.2f} s (k*={kstar}, {confl} conflicts) | GPU batch loop {gpu}", flush=True)

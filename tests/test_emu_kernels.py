@@ -290,12 +290,17 @@ def test_emulated_solver_loop_sweep_prints_the_reference_messages():
     grid = make_grid("ex1")
     enc = Encoding.encode(platform_defs("1x1"), grid)
     lines = []
-    hist = solver_loop_sweep(grid, enc, PlatformLimits({(1, 1): 8}), out=lines.append,
-                             make_solver=lambda: emu_solver(workers=9, slice_conflicts=20))
-    sat = [h for h in hist if h["result"] == SolverResult.Sat]
-    assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == 2 and 1 <= len(sat) <= 2           # k* = 3
-    assert sat[-1]["count"] == 3 and all(h["valid"] for h in sat)
-    assert "Solution found (3 platforms total)" in lines and lines[-1] == "No solution found for the current constraints"
+    # specialize_after: None = the batch runs to the cut;  0 = it hands over to the sequential loop (a fresh CNF per
+    # bound, as the reference poses them) as soon as at most two bounds are open
+    for spec in (None, 0.0):
+        lines = []
+        hist = solver_loop_sweep(grid, enc, PlatformLimits({(1, 1): 8}), out=lines.append, specialize_after=spec,
+                                 make_solver=lambda: emu_solver(workers=9, slice_conflicts=20))
+        sat = [h for h in hist if h["result"] == SolverResult.Sat]
+        assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == 2 and len(sat) >= 1           # k* = 3
+        assert sat[-1]["count"] == 3 and all(h["valid"] for h in sat)
+        assert [h["count"] for h in sat] == sorted([h["count"] for h in sat], reverse=True)
+        assert "Solution found (3 platforms total)" in lines and lines[-1] == "No solution found for the current constraints"
     with pytest.raises(ValueError):
         solver_loop_sweep(grid, enc, PlatformLimits({(1, 1): 3}, weights={(1, 1): 2}, weight_limit=5))
 

