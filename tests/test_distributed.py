@@ -51,7 +51,7 @@ def test_two_rank_cut_exchange_gloo():
     assert m0 == m1 == [1.0] * 8                                                   # broadcast from the rank owning k=14
 
 
-def _sharded_worker(rank, world, port, q, terrain, pset, k0):
+def _sharded_worker(rank, world, port, q, terrain, pset, k0, spec=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -66,7 +66,7 @@ def _sharded_worker(rank, world, port, q, terrain, pset, k0):
     hist = solver_loop_sweep_sharded(grid, enc, PlatformLimits({(1, 1): k0}), out=lines.append, time_limit=600,
                                      make_solver=lambda: Mi355Sat(_lib_override=emu_lib(), workers=6, slice_conflicts=30, simp=-1,
                                                                   seed=100 + rank),
-                                     stats_out=st)
+                                     stats_out=st, specialize_after=spec)
     best = [h for h in hist if h["result"].name == "Sat"][-1]
     model = best["model"]
     model = model.tolist() if hasattr(model, "tolist") else list(model)
@@ -75,15 +75,17 @@ def _sharded_worker(rank, world, port, q, terrain, pset, k0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("terrain,pset,k0,kstar", [("rect8x8", "1x1", 8, 4), ("ex1", "1x1", 10, 3)])
-def test_two_rank_sharded_sweep_with_real_solves_gloo(terrain, pset, k0, kstar):
+@pytest.mark.parametrize("terrain,pset,k0,kstar,spec", [("rect8x8", "1x1", 8, 4, None), ("ex1", "1x1", 10, 3, None),
+                                                        ("ex1", "1x1", 10, 3, 0.0)])
+def test_two_rank_sharded_sweep_with_real_solves_gloo(terrain, pset, k0, kstar, spec):
     """SURVEY 8e end to end on CPU: two ranks over gloo, each driving the product's search kernels (emulator
     build) on its shard of bounds k = k_hi - rank - i*world; the cut all-reduce + model broadcast make both
     ranks return the same history, and the optimum is the golden one."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, terrain, pset, k0)) for r in range(2)]
+    # spec = 0.0: the batch hands over to the replica tail (every rank the same bound with its own CNF and seed)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, terrain, pset, k0, spec)) for r in range(2)]
     for p in procs:
         p.start()
     out = sorted(q.get(timeout=900) for _ in procs)
@@ -97,7 +99,7 @@ def test_two_rank_sharded_sweep_with_real_solves_gloo(terrain, pset, k0, kstar):
     assert sat[-1][2] == kstar and all(h[3] for h in sat)
     assert lines0[-1] == "No solution found for the current constraints" and lines1 == []   # rank 0 speaks
     assert f"Solution found ({kstar} platforms total)" in lines0
-    assert c0 > 0 and c1 > 0                                        # both ranks really searched
+    assert c0 > 0 and c1 > 0                                        # both ranks really searched (the batch part)
     # the agreed model is a model of the CNF at its own count (checked with the oracle)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np

@@ -73,12 +73,17 @@ def _bcast_first(rec, n_model, device):
 
 
 def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=print, time_limit=None, exchange_every=1,
-                              device="cpu", stats_out=None):
+                              device="cpu", stats_out=None, specialize_after=2.0):
     """The decreasing-k refinement (crates/repl/src/main.rs:280-366, `-l1:K` form) sharded over the ranks of
     the default process group.  Every rank returns the same history (records shaped like
     solver_loop's: the start bound, the best layout, the refuted bound); rank 0 prints the reference's
     messages.  `device` is where the two tiny collectives live ("cuda" under nccl/RCCL, "cpu" under gloo).
-    stats_out (dict) receives this rank's solver counters and the time to the cut."""
+    stats_out (dict) receives this rank's solver counters and the time to the cut.
+
+    As in loop.py::solver_loop_sweep the batch is only the way DOWN: once it has run `specialize_after` seconds and at
+    most two bounds are open anywhere, it ends and the ranks pose the next bound (best count - 1) the way the reference
+    does, with its own CNF - every rank the same bound with its own seed (replicas: a single refutation does not
+    shard), polling each other every slice; the first verdict is everybody's."""
     if set(limits.card_limits) != {(1, 1)} or limits.weights or limits.weight_limit is not None:
         raise ValueError("solver_loop_sweep_sharded handles a single 1x1 cardinality limit")
     rank, world = _world()
@@ -127,7 +132,7 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
     solver.sweep_drop([idx[k] for k in ks if k not in active])
     local, looked, unsat_k = {k: ("open", None) for k in ks}, set(), -1
     t0 = time.perf_counter()
-    step, interrupted, cut = 0, False, None
+    step, interrupted, cut, specialize = 0, False, None, False
     while True:
         res, _ = solver.sweep_step()
         step += 1
@@ -159,6 +164,13 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
         # what the global cut leaves open: unsat_k < k < best_c.  Withdraw the rest; a rank whose shard has
         # nothing open any more takes up everything that is still open anywhere.
         open_ks = [k for k in ks if unsat_k < k < best_c]
+        if specialize_after is not None and len(open_ks) <= 2:      # (the cut is agreed, the clocks are not: agree on leaving too)
+            go = torch.tensor([1 if time.perf_counter() - t0 > specialize_after else 0], dtype=torch.int64, device=device)
+            if world > 1:
+                dist.all_reduce(go, op=dist.ReduceOp.MAX)
+            if int(go[0]):
+                specialize = True
+                break
         want = [k for k in open_ks if k in mine and local[k][0] == "open"] or [k for k in open_ks if local[k][0] == "open"]
         want = set(want)
         solver.sweep_drop([idx[k] for k in active - want if local[k][0] == "open"])
@@ -183,6 +195,9 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
         if best_c == 0:
             say("Found a solution with no platforms - aborting")
             return history
+    if specialize:
+        left = None if time_limit is None else max(0.0, time_limit - dt)
+        return history + _replica_tail(grid, encoding, best_c, make_solver, say, left, device, n_model, stats_out)
     if interrupted:
         history.append({"k": best_c - 1, "result": SolverResult.Interrupted, "count": None, "valid": None, "seconds": dt})
         say("Solver interrupted")
@@ -190,6 +205,64 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
         history.append({"k": best_c - 1, "result": SolverResult.Unsat, "count": None, "valid": None, "seconds": dt})
         say("No solution found for the current constraints")
     return history
+
+
+def _replica_tail(grid, encoding, best_c, make_solver, say, time_limit, device, n_model, stats_out):
+    """The reference's sequential loop from `best_c` on, every rank a replica with its own seed: each bound gets its own
+    CNF (main.rs:292-293) and is stepped slice by slice; after every slice one all-reduce tells whether any rank has
+    the verdict, a model comes from its owner."""
+    rank, world = _world()
+    history, t0 = [], time.perf_counter()
+    while True:
+        k = best_c - 1
+        cnf = encoding.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+        solver = make_solver()
+        solver.add_cnf(cnf.lits, cnf.offsets)
+        solver.reserve(cnf.n_vars)
+        solver.sweep_begin([[]])
+        tk = time.perf_counter()
+        verdict = 0
+        while True:
+            res, _ = solver.sweep_step()
+            late = 1 if (time_limit is not None and time.perf_counter() - t0 > time_limit) else 0
+            t = torch.tensor([res[0].value, late], dtype=torch.int64, device=device)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            verdict = int(t[0])
+            if verdict or int(t[1]):
+                break
+        model = torch.zeros(n_model, dtype=torch.float32, device=device)
+        if verdict == SolverResult.Sat.value:
+            owner = torch.tensor([rank if res[0] == SolverResult.Sat else -1], dtype=torch.int64, device=device)
+            if world > 1:
+                dist.all_reduce(owner, op=dist.ReduceOp.MAX)
+            if int(owner[0]) == rank:
+                model.copy_(torch.as_tensor(np.asarray(solver.sweep_solution_of(0, n_model), dtype=np.float32)))
+            if world > 1:
+                dist.broadcast(model, src=int(owner[0]))
+        solver.sweep_end()
+        if stats_out is not None:
+            stats_out.setdefault("tail_conflicts", 0)
+            stats_out["tail_conflicts"] += solver.stats()["conflicts"]
+        solver.close()
+        dt = time.perf_counter() - tk
+        if verdict == SolverResult.Unsat.value:
+            history.append({"k": k, "result": SolverResult.Unsat, "count": None, "valid": None, "seconds": dt})
+            say("No solution found for the current constraints")
+            return history
+        if verdict == 0:
+            history.append({"k": k, "result": SolverResult.Interrupted, "count": None, "valid": None, "seconds": dt})
+            say("Solver interrupted")
+            return history
+        lay = PlatformLayout.from_assignment(model.cpu().numpy().astype(np.int8), encoding)
+        best_c = lay.platform_count()
+        rec = {"k": k, "result": SolverResult.Sat, "count": best_c, "valid": lay.validate(grid).is_valid(), "seconds": dt,
+               "layout": lay, "model": model}
+        history.append(rec)
+        if best_c == 0:
+            say("Found a solution with no platforms - aborting")
+            return history
+        _say_layout(say, lay, best_c, rec["valid"])
 
 
 def _say_layout(say, layout, count, valid):
