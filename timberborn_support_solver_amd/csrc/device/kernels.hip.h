@@ -89,7 +89,7 @@ struct Wk {
     uint32_t c_props, c_watch, c_move, c_enq, c_dec, c_steps, c_redo;
     uint32_t c_cl_lit;  // per lane
 #ifdef MS_PROFILE
-    u64 prof[PF_N];
+    u64 prof[PF_N + 1];        // phase cycles + [PF_N] = resolution steps of conflict analysis
 #endif
 };
 
@@ -870,6 +870,9 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
             }
         }
         index--;
+#ifdef MS_PROFILE
+        w.prof[PF_N]++;                    // resolution steps (diagnostic build)
+#endif
         const int v = p >> 1;
         const MsVarRec pr = VREC[v];       // reason and, for a long reason, where its literals are: one round trip
         const int r = uni(pr.reason);
@@ -1223,7 +1226,7 @@ DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const
     w.confl_kind = 0; w.confl_cref = 0; w.confl_a = 0; w.confl_b = 0; w.confl_c = 0;
     w.c_props = w.c_watch = w.c_move = w.c_enq = w.c_dec = w.c_steps = w.c_redo = 0; w.c_cl_lit = 0;
 #ifdef MS_PROFILE
-    for (int i = 0; i < PF_N; i++) w.prof[i] = 0;
+    for (int i = 0; i <= PF_N; i++) w.prof[i] = 0;
 #endif
     if (LV) {  // stage the packed assignment words in LDS for this slice
         const uint32_t* gv = WKA(uint32_t, val);
@@ -1253,7 +1256,7 @@ DEV void wk_store(Wk& w, const MsShared& sh, const MsLayout& L, u64 cycles) {
         s->slice_cycles += cycles;
         s->n_steps += w.c_steps; s->n_redo += w.c_redo;
 #ifdef MS_PROFILE
-        for (int i = 0; i < PF_N; i++) s->prof[i] += w.prof[i];
+        for (int i = 0; i <= PF_N; i++) s->prof[i] += w.prof[i];
 #endif
     }
 }
@@ -1343,7 +1346,10 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         if (w.lane == 0) *ls.proof_len = o + (uint32_t)lr.n + 1;
         wave_fence();
     }
-    if (ls.share_pool && lr.n <= (int)ls.share_max_len && (lr.n <= 2 || lr.lbd <= ls.share_max_lbd) && ls.exp_n < MS_EXPORT_RECS) {
+#ifndef MS_SHARE_SMALL
+#define MS_SHARE_SMALL 2     // clauses up to this size are exchanged whatever their LBD
+#endif
+    if (ls.share_pool && lr.n <= (int)ls.share_max_len && (lr.n <= MS_SHARE_SMALL || lr.lbd <= ls.share_max_lbd) && ls.exp_n < MS_EXPORT_RECS) {
         int32_t* rec = WK_PTR(int32_t, w, L, exp) + ls.exp_n * MS_SHARE_REC;
         if (w.lane <= lr.n)
             rec[w.lane] = w.lane == 0 ? (int)((uint32_t)lr.n | ((lr.lbd > 255u ? 255u : lr.lbd) << 6) | (ls.wid << 14))

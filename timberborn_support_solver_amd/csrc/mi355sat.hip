@@ -1133,7 +1133,10 @@ void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
         static const char* nm[] = {"offsets", "binary", "ternary", "long", "close", "analyze", "backjump+learn", "decide", "reduce"};
         fprintf(stderr, "[mi355sat] phase cycle shares of %.3e worker-cycles:", (double)cyc);
         for (int i = 0; i < 9; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)prof[i] / (double)cyc);
-        fprintf(stderr, "\n");
+        uint64_t confl = 0, ll = 0, lt = 0;
+        for (auto& st : sts) { confl += st.conflicts; ll += st.learnt_lits_total; lt += st.learnt_total; }
+        fprintf(stderr, "; resolution steps per conflict %.1f, learnt clause %.1f literals\n", (double)prof[9] / (double)std::max<uint64_t>(1, confl),
+                (double)ll / (double)std::max<uint64_t>(1, lt));
     }
 }
 
