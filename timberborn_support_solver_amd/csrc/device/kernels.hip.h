@@ -808,6 +808,14 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     int path_c = 0, p = -1, n_out = 1, n_clear = 0;
     int index = w.trail_n - 1;
     int chunk_hi = -1, chunk_l = 0;   // cached chunk of the trail (LV)
+    // (LV) per lane: the variable record of the lane's trail literal and the head of its reason - for a long reason its
+    // first 8 literals, for a ternary one the clause - fetched for ALL marked literals of the chunk at once (two round
+    // trips for the lot) and kept in registers: most resolution steps then touch no memory at all
+    MsVarRec c_rec = MsVarRec{0, MS_REASON_NONE, 0, 0, 0, 0};
+    int4 c_l0 = make_int4(0, 0, 0, 0), c_l1 = make_int4(0, 0, 0, 0);
+    bool c_ok = false;
+    int4 pre0 = make_int4(0, 0, 0, 0), pre1 = make_int4(0, 0, 0, 0);   // uniform: head of the clause about to be visited
+    int pre_n = 0;
     const int dl = w.n_levels;
     int kind = w.confl_kind, cref = w.confl_cref, ba = w.confl_a, bb = w.confl_b, bc = w.confl_c;
     for (;;) {
@@ -819,9 +827,14 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
             if ((uint32_t)cref >= sh.n_orig && w.lane == 0) lc_lbd[cref - sh.n_orig] |= 0x80000000u;  // used
             for (int k0 = 0; k0 < size; k0 += MS_WAVE) {
                 int k = k0 + w.lane;
-                int q = k < size ? cl[k] : 0;
+                int q = 0;
+                if (k < pre_n) {   // the first literals came with the prefetch of the reason (uniform values, lane k takes the k-th)
+                    q = k < 4 ? (k < 2 ? (k == 0 ? pre0.x : pre0.y) : (k == 2 ? pre0.z : pre0.w))
+                              : (k < 6 ? (k == 4 ? pre1.x : pre1.y) : (k == 6 ? pre1.z : pre1.w));
+                } else if (k < size) q = cl[k];
                 analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, k < size && q != p, q, dl, path_c, n_out, n_clear);
             }
+            pre_n = 0;
         } else {
             int q = w.lane == 0 ? ba : (w.lane == 1 ? bb : bc);
             analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, w.lane < kind && q != p, q, dl, path_c, n_out, n_clear);
@@ -837,6 +850,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
                     chunk_hi = index;
                     const int i = chunk_hi - w.lane;
                     chunk_l = i >= 0 ? WKA(int32_t, trail)[i] : 0;
+                    c_ok = false;
                 }
                 const int pos = chunk_hi - w.lane;
                 const bool ok = pos >= 0 && pos <= index && seen_get<LV>(w, sh, L, chunk_l >> 1);
@@ -874,6 +888,45 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
         w.prof[PF_N]++;                    // resolution steps (diagnostic build)
 #endif
         const int v = p >> 1;
+        if (LV) {
+            const int f = chunk_hi - (index + 1);      // the lane that holds p
+            if (!bcast((int)c_ok, f)) {
+                // fetch for every marked literal of the chunk that is still to come (p included): records, then reason heads
+                const int pos = chunk_hi - w.lane;
+                const bool want = !c_ok && pos >= 0 && pos <= index + 1 && seen_get<LV>(w, sh, L, chunk_l >> 1);
+                if (want) c_rec = VREC[chunk_l >> 1];
+                if (want) {
+                    const int rr = c_rec.reason;
+                    if (rr >= 0 && c_rec.size > 0) {
+                        const int32_t* cl = ((uint32_t)rr < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + c_rec.start;
+                        c_l0 = *(const int4*)cl;
+                        if (c_rec.size > 4) c_l1 = *(const int4*)(cl + 4);
+                    } else if (rr < 0 && MS_IS_TERN_REASON(rr)) {
+                        const int e = MS_TERN_REASON_ENTRY(rr);
+                        const int2 tp = ((const int2*)sh.tern_pairs)[e];
+                        c_l0 = make_int4(sh.tern_owner[e] ^ 1, tp.x, tp.y, 0);
+                    }
+                    c_ok = true;
+                }
+            }
+            const int r = bcast(c_rec.reason, f);
+            wave_fence();
+            if (w.lane == 0) seen_clr<LV>(w, sh, L, v);
+            lds_fence();
+            path_c--;
+            if (path_c <= 0) break;
+            if (r >= 0) {
+                kind = 1; cref = r; bb = bcast((int)c_rec.start, f); bc = bcast((int)c_rec.size, f);
+                if (bc > 0) {
+                    pre0 = make_int4(bcast(c_l0.x, f), bcast(c_l0.y, f), bcast(c_l0.z, f), bcast(c_l0.w, f));
+                    pre1 = make_int4(bcast(c_l1.x, f), bcast(c_l1.y, f), bcast(c_l1.z, f), bcast(c_l1.w, f));
+                    pre_n = bc < 8 ? bc : 8;
+                }
+            } else if (MS_IS_TERN_REASON(r)) { kind = 3; ba = bcast(c_l0.x, f); bb = bcast(c_l0.y, f); bc = bcast(c_l0.z, f); }
+            else if (MS_IS_BIN_REASON(r)) { kind = 2; ba = p; bb = MS_BIN_REASON_LIT(r); }
+            else { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
+            continue;
+        }
         const MsVarRec pr = VREC[v];       // reason and, for a long reason, where its literals are: one round trip
         const int r = uni(pr.reason);
         wave_fence();
