@@ -30,15 +30,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def _cpu_leg(job):
-    """One process of the all-cores CPU baseline: the oracle's CDCL on one (k) instance for a conflict budget."""
-    lits, offs, assumps, budget = job
+def _cpu_leg(path, assumps, budget):
+    """One process of the all-cores CPU baseline (bench.py --cpu-leg ...): the oracle's CDCL on one at-most-k instance
+    for a conflict budget; prints "propagations conflicts"."""
+    import numpy as np
     from oracle import oracle as ora
+    z = np.load(path)
     o = ora.OracleSolver()
-    o.add_cnf(lits, offs)
-    o.solve(assumps, conflict_budget=budget)
+    o.add_cnf(z["lits"], z["offs"])
+    o.solve([int(x) for x in assumps.split(",") if x], conflict_budget=int(budget))
     st = o.stats()
-    return st["propagations"], st["conflicts"]
+    print(st["propagations"], st["conflicts"])
 
 
 def measured_copy_gbs(torch, device_index):
@@ -61,6 +63,8 @@ def measured_copy_gbs(torch, device_index):
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-leg":
+        return _cpu_leg(sys.argv[2], sys.argv[3], sys.argv[4])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
@@ -173,6 +177,11 @@ def main():
         tot = [float(t[0]), float(tm[0]), float(t[1])]
     total_props, max_dt, total_confl = tot
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"timed region done: {total_props / max_dt:.3e} propagations/s")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:   # reported baseline: rank 0 at N=1 only
         import numpy as np
@@ -189,19 +198,29 @@ def main():
                "sample": f"rect {n}x{n} {args.platforms}, at-most-{k_cpu}, first {so['conflicts']} conflicts "
                          f"({dtc:.1f} s) of the oracle's single-thread CDCL restatement (not rustsat-glucose)",
                "conflicts_per_s": so["conflicts"] / max(dtc, 1e-9)}
+        note(f"cpu baseline, 1 core: {cpu['value']:.3e} propagations/s in {dtc:.1f} s")
         # all host cores, one independent (k) instance per core, same conflict budget each
-        import multiprocessing as mp
+        # (child processes of their own, started with subprocess: this process has initialised HIP, whose runtime threads do
+        # not survive a fork)
+        import subprocess
+        import tempfile
         ncores = min(os.cpu_count() or 1, args.cpu_cores) if args.cpu_cores > 0 else (os.cpu_count() or 1)
-        jobs = [(np_lits, np_offs, assumption_sets[i % len(ks)], args.cpu_conflicts) for i in range(ncores)]
-        tc = time.perf_counter()
-        with mp.get_context("fork").Pool(ncores) as pool:
-            rs = pool.map(_cpu_leg, jobs)
-        dta = time.perf_counter() - tc
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "cnf.npz")
+            np.savez(path, lits=np_lits, offs=np_offs)
+            tc = time.perf_counter()
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-leg", path,
+                                       ",".join(str(int(l)) for l in assumption_sets[i % len(ks)]), str(args.cpu_conflicts)],
+                                      stdout=subprocess.PIPE, text=True) for i in range(ncores)]
+            rs = [tuple(int(x) for x in p.communicate()[0].split()) for p in procs]
+            dta = time.perf_counter() - tc
         cpu["all_cores"] = {"value": sum(r[0] for r in rs) / max(dta, 1e-9), "unit": "propagations/s", "cores": ncores,
                             "conflicts_per_s": sum(r[1] for r in rs) / max(dta, 1e-9),
                             "sample": f"{ncores} processes, one at-most-k instance each (k cycling {ks[0]}..{ks[-1]}), "
                                       f"{args.cpu_conflicts} conflicts each, {dta:.1f} s wall"}
 
+    if cpu and "all_cores" in cpu:
+        note(f"cpu baseline, {cpu['all_cores']['cores']} cores: {cpu['all_cores']['value']:.3e} propagations/s")
     solver.sweep_end()
     solver.close()
 
@@ -261,7 +280,8 @@ def main():
             cnt = PlatformLayout.from_assignment(o.model(ck.n_vars)[:e2.n_vars], e2).platform_count()
             k = cnt - 1
         cpu_s = time.perf_counter() - tc
-        first_unsat = {"instance": f"rect {m} {m} {args.platforms}, solver_loop_sweep from k={k0} (first bound alone, then all lower bounds as one batch)", "optimum_k": kstar,
+        note(f"first UNSAT rect {m}: gpu {gpu_s:.2f} s (k* {kstar}), cpu {cpu_s:.2f} s (k* {cpu_kstar})")
+        first_unsat = {"instance": f"rect {m} {m} {args.platforms}, solver_loop_sweep from k={k0} (first bound alone, the lower bounds as one batch on the way down, the last bounds with their own CNF)", "optimum_k": kstar,
                        "gpu_seconds": gpu_s if kstar is not None else None, "cpu_seconds": cpu_s if cpu_kstar is not None else None,
                        "cpu_optimum_k": cpu_kstar, "cpu_kind": "port (oracle CDCL restatement, 1 core)",
                        "note": "rect 64 64 to a proven first UNSAT is out of reach for both sides (area bound k* >= 43)"}
