@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--cpu-conflicts", type=int, default=200000, help="conflict budget of the CPU baseline sample (~10-15 s)")
     ap.add_argument("--first-unsat-size", type=int, default=24, help="rect size of the wall-clock-to-first-UNSAT rung (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the all-cores CPU leg (0 = all host cores)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the all-cores CPU leg (0 = the cores this process may use, at most 16)")
     ap.add_argument("--var-order", type=int, default=0, help="0 caller's numbering (default), 1 locality order (A/B)")
     ap.add_argument("--share", type=int, default=-1, help="learnt-clause exchange in the THROUGHPUT sweep: -1 off (default: the "
                     "exchange makes the trajectory, and with it the rate, depend on slice timing), 0 on.  The first-UNSAT line always "
@@ -204,7 +204,11 @@ def main():
         # not survive a fork)
         import subprocess
         import tempfile
-        ncores = min(os.cpu_count() or 1, args.cpu_cores) if args.cpu_cores > 0 else (os.cpu_count() or 1)
+        # the host cores this process may use: its affinity mask, at most 16 (a one-GPU box's CPU share; os.cpu_count()
+        # is the whole node's)
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncores = min(avail, args.cpu_cores if args.cpu_cores > 0 else 16)
+        note(f"cpu baseline, all cores: starting {ncores} processes")
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, "cnf.npz")
             np.savez(path, lits=np_lits, offs=np_offs)
