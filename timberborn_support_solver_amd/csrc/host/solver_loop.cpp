@@ -142,11 +142,8 @@ std::vector<LoopIteration> solver_loop_sweep(const WorldGrid& world, const Encod
             }
         // The batch is the fast way DOWN, not the fast way to the last refutation (a bound posed as an assumption
         // over a looser bound's totalizer is refuted much more slowly than with its own CNF: loop.py): after two
-        // seconds with at most two bounds open, the sequential loop finishes from the best count.
-        size_t n_open = 0;
-        for (size_t i = 0; i < ks.size(); i++)
-            if (res[i] == 0 && (best_c < 0 || (long)ks[i] < best_c) && (long)ks[i] > unsat_k) n_open++;
-        if (n_open <= 2 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) { specialize = true; break; }
+        // seconds the sequential loop finishes from the best count.
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) { specialize = true; break; }
         std::vector<double> weights(ks.size(), 0.02);
         for (size_t i = 0; i < ks.size(); i++) if ((long)ks[i] == hi || (long)ks[i] == lo) weights[i] = 1.0;
         if (mi355sat_sweep_set_weights(s, weights.data(), weights.size()) < 0) fail("sweep_set_weights");

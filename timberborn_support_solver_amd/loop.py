@@ -79,9 +79,10 @@ def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_in
     refutation: a bound posed as an assumption over the totalizer of a looser one is refuted much more slowly than
     the same bound as the reference poses it, with its own CNF (measured on rect 26x26: k = 10 not refuted in 160 s
     and 1.8e8 conflicts inside the batch, 60-70 s and 5-7e7 conflicts on its own: at level 0 the bound's unit cuts
-    the totalizer down, as an assumption it adds a literal and a level to every learnt clause).  So once the batch
-    has run for `specialize_after` seconds and at most two bounds are still open, it ends and the reference's own
-    sequential loop (a fresh solver and a fresh CNF per bound, main.rs:292-295) finishes from the best count."""
+    the totalizer down, as an assumption it adds a literal and a level to every learnt clause).  So the batch runs
+    for `specialize_after` seconds - on rect 26x26 that takes the count from 25 to 11 - then ends, and the
+    reference's own sequential loop (a fresh solver and a fresh CNF per bound, main.rs:292-295) finishes from the
+    best count.  (Waiting until at most two bounds were open cost rect 32x32 166 s in the batch.)"""
     if set(limits.card_limits) != {(1, 1)} or limits.weights or limits.weight_limit is not None:
         raise ValueError("solver_loop_sweep handles a single 1x1 cardinality limit; use solver_loop / weight_loop")
     # first iteration exactly as the reference makes it (the start bound is loose: its totalizer would only
@@ -168,8 +169,7 @@ def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limi
         if flag or (time_limit is not None and time.perf_counter() - t0 > time_limit):
             interrupted = True
             break
-        n_open = sum(1 for k, r in zip(ks, res) if r == SolverResult.Interrupted and (best_c is None or k < best_c) and k > unsat_k)
-        if specialize_after is not None and time.perf_counter() - t0 > specialize_after and n_open <= 2:
+        if specialize_after is not None and time.perf_counter() - t0 > specialize_after:
             specialize = True
             break
         solver.sweep_drop([i for i, k in enumerate(ks) if res[i] == SolverResult.Interrupted and

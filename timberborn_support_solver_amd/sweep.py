@@ -80,8 +80,8 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
     messages.  `device` is where the two tiny collectives live ("cuda" under nccl/RCCL, "cpu" under gloo).
     stats_out (dict) receives this rank's solver counters and the time to the cut.
 
-    As in loop.py::solver_loop_sweep the batch is only the way DOWN: once it has run `specialize_after` seconds and at
-    most two bounds are open anywhere, it ends and the ranks pose the next bound (best count - 1) the way the reference
+    As in loop.py::solver_loop_sweep the batch is only the way DOWN: once it has run `specialize_after` seconds it
+    ends and the ranks pose the next bound (best count - 1) the way the reference
     does, with its own CNF - every rank the same bound with its own seed (replicas: a single refutation does not
     shard), polling each other every slice; the first verdict is everybody's."""
     if set(limits.card_limits) != {(1, 1)} or limits.weights or limits.weight_limit is not None:
@@ -164,7 +164,7 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
         # what the global cut leaves open: unsat_k < k < best_c.  Withdraw the rest; a rank whose shard has
         # nothing open any more takes up everything that is still open anywhere.
         open_ks = [k for k in ks if unsat_k < k < best_c]
-        if specialize_after is not None and len(open_ks) <= 2:      # (the cut is agreed, the clocks are not: agree on leaving too)
+        if specialize_after is not None:      # (the cut is agreed, the clocks are not: agree on leaving too)
             go = torch.tensor([1 if time.perf_counter() - t0 > specialize_after else 0], dtype=torch.int64, device=device)
             if world > 1:
                 dist.all_reduce(go, op=dist.ReduceOp.MAX)
