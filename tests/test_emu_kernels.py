@@ -423,3 +423,37 @@ def test_emulated_subsumption_kernel_removes_and_strengthens():
         o.add_cnf(lits, offs)
         assert r.value == o.solve(a), a
     s.close()
+
+
+def test_emulated_sweep_priorities_and_reopening_keep_the_answers():
+    """mi355sat_sweep_set_weights / mi355sat_sweep_reopen are scheduling only: whatever the caller's priorities and
+    however often bounds are withdrawn and taken up again, every decided bound has its golden verdict."""
+    from timberborn_support_solver_amd.solver import SolverError
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 8}), sweep=True)
+    ks = [8, 6, 5, 4, 3, 2]                                                    # k* = 4
+    sets = [[-int(cnf.card_outputs[k])] if k < 8 else [] for k in ks]
+    s = emu_solver(workers=12, slice_conflicts=15)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    s.sweep_begin(sets)
+    with pytest.raises(SolverError):
+        s.sweep_set_weights([1.0, 2.0])                                        # one weight per instance
+    with pytest.raises(SolverError):
+        s.sweep_set_weights([1.0] * 5 + [-1.0])
+    s.sweep_drop([0, 1, 2])                                                    # start with the low bounds only
+    s.sweep_set_weights([0.02, 0.02, 0.02, 1.0, 0.02, 1.0])
+    res = None
+    for step in range(600):
+        res, nd = s.sweep_step()
+        if step == 3:
+            s.sweep_reopen([0, 1, 2, 5])                                       # (5 was never withdrawn: ignored)
+            s.sweep_set_weights([1.0, 0.02, 0.02, 0.02, 0.02, 1.0])
+        if all(r != SolverResult.Interrupted for r in res):
+            break
+    s.sweep_end()
+    assert [r.name for r in res] == ["Sat", "Sat", "Sat", "Sat", "Unsat", "Unsat"]
+    for i, k in enumerate(ks):
+        if res[i] == SolverResult.Sat:
+            check_sat_answer(cnf, s.solution_of(i, cnf.n_vars), enc, grid, k)
+    s.close()
