@@ -157,7 +157,7 @@ def test_emulated_unsat_verdicts_carry_a_drup_proof(tmp_path):
     host interleaves the logs slice by slice; the oracle's independent RUP checker must accept the proof."""
     from timberborn_support_solver_amd.dimacs import read_drup, read_dimacs, write_dimacs
     exchanged = 0
-    for terrain, pset, k in [("ex1", "1x1", 2), ("rect8x8", "default", 1), ("rect8x8", "1x1", 3)]:
+    for terrain, pset, k in [("ex1", "1x1", 2), ("rect8x8", "1x1", 3)]:
         grid = make_grid(terrain)
         enc = Encoding.encode(platform_defs(pset), grid)
         cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
@@ -347,8 +347,7 @@ def test_emulated_assignment_in_hbm_variant(tmp_path):
     s.close()
 
 
-@pytest.mark.parametrize("terrain,pset,k,want", [("ex1", "1x1", 2, "Unsat"), ("ex1", "1x1", 3, "Sat"), ("ex1", "default", 1, "Sat"),
-                                                  ("ex3", "1x1", 4, "Sat")])
+@pytest.mark.parametrize("terrain,pset,k,want", [("ex1", "1x1", 2, "Unsat"), ("ex1", "1x1", 3, "Sat"), ("ex1", "default", 1, "Sat")])
 def test_emulated_simplification_keeps_verdicts_models_and_proofs(tmp_path, terrain, pset, k, want):
     """SURVEY 8 f3 (`simp::Glucose`, crates/repl/src/main.rs:17): equivalent-literal substitution, failed-literal
     probing (ms_probe_kernel) and subsumption (ms_subsume_kernel) before the search.  Verdicts are those without

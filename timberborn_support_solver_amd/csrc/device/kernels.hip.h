@@ -1500,8 +1500,11 @@ DEV_COLD void on_fixpoint(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
 // ONE = the build for a fleet of at most one worker per SIMD (<= 1024 workers): the whole register file of the
 // SIMD is the worker's (no spills, no scratch copies: the per-conflict and per-fixpoint code is inlined), which is
 // what counts when nothing else hides a wave's latencies.
-template <bool LV, bool ONE>
-__global__ __launch_bounds__(MS_WAVE, ONE ? 1 : MS_SEARCH_WAVES_PER_SIMD) void ms_search_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
+// WPS = waves per SIMD the build is compiled for: 1 (the ONE build above), 2 (<= 2048 workers: 256 registers per wave, no
+// spills, the per-conflict code still a call) or MS_SEARCH_WAVES_PER_SIMD (the full fleet).
+template <bool LV, int WPS>
+__global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
+    constexpr bool ONE = WPS == 1;
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
     __shared__ uint32_t s_hist[64];

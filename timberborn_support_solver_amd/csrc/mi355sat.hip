@@ -1198,14 +1198,20 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     const uint32_t dyn = lds ? s.lds_val_bytes : 0;
     HIPCHK(hipEventRecord(s.ev0, s.stream));
     if (mode == 0) {
-        const bool one = s.opts.one_per_simd >= 0 && active <= 1024;   // at most one worker per SIMD: the no-spill build
+        // the build compiled for the launch's waves per SIMD: 1 (<= 1024 workers: the SIMD's whole register file, everything
+        // inlined), 2 (<= 2048: no spills either), else the full fleet's
+        const int wps = s.opts.one_per_simd < 0 ? MS_SEARCH_WAVES_PER_SIMD : (active <= 1024 ? 1 : (active <= 2048 ? 2 : MS_SEARCH_WAVES_PER_SIMD));
+#define MS_LAUNCH_SEARCH(LVV, W) hipLaunchKernelGGL((ms_search_kernel<LVV, W>), dim3(active), dim3(MS_WAVE), (LVV) ? dyn : 0, s.stream, s.sh, s.L, s.d_slabs.p, prm)
         if (lds) {
-            if (one) hipLaunchKernelGGL((ms_search_kernel<true, true>), dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
-            else hipLaunchKernelGGL((ms_search_kernel<true, false>), dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+            if (wps == 1) MS_LAUNCH_SEARCH(true, 1);
+            else if (wps == 2) MS_LAUNCH_SEARCH(true, 2);
+            else MS_LAUNCH_SEARCH(true, MS_SEARCH_WAVES_PER_SIMD);
         } else {
-            if (one) hipLaunchKernelGGL((ms_search_kernel<false, true>), dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
-            else hipLaunchKernelGGL((ms_search_kernel<false, false>), dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
+            if (wps == 1) MS_LAUNCH_SEARCH(false, 1);
+            else if (wps == 2) MS_LAUNCH_SEARCH(false, 2);
+            else MS_LAUNCH_SEARCH(false, MS_SEARCH_WAVES_PER_SIMD);
         }
+#undef MS_LAUNCH_SEARCH
     } else if (mode == 2) {
         if (lds) hipLaunchKernelGGL(ms_probe_kernel<true>, dim3(active), dim3(MS_WAVE), dyn, s.stream, s.sh, s.L, s.d_slabs.p, prm);
         else hipLaunchKernelGGL(ms_probe_kernel<false>, dim3(active), dim3(MS_WAVE), 0, s.stream, s.sh, s.L, s.d_slabs.p, prm);
