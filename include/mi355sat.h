@@ -97,6 +97,9 @@ typedef struct mi355sat_opts {
                                   interface: models, assumptions and proofs stay in the caller's variables. */
     int32_t phase_mix;         /* 0 = default: every worker starts with all saved phases FALSE (no platform anywhere);
                                   1 = portfolio of initial phases: a quarter of the workers start TRUE, a quarter at random */
+    int32_t rephase;           /* rephasing to the best assignment (the polarities of the longest conflict-free assignment a worker
+                                  has seen become its saved phases every 2000, 4000, 6000, ... conflicts, at a restart):
+                                  0 = default: every second worker, 1 = all workers, -1 = none */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
 } mi355sat_opts;

@@ -1330,6 +1330,12 @@ struct LoopState {
     const int4* share_pool;
     u64 share_n, share_pos, n_exported, n_imported, n_imported_units, last_import_confl;
     uint32_t share_slots, share_max_lbd, share_max_len, share_interval, exp_n, wid;
+    // best-phase rephasing (CaDiCaL's "rephase to best"): the polarities of the longest conflict-free assignment seen
+    // become the saved phases every so often - a strong heuristic on satisfiable bounds near the optimum
+    int best_trail;
+    uint32_t n_rephase;
+    u64 next_rephase;
+    bool rephase;
 };
 
 // Attach the records of the global ring this worker has not seen yet.  Called at decision level 0
@@ -1384,6 +1390,17 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     ls.trail_avg += ((double)w.trail_n - ls.trail_avg) * (1.0 / 5000.0);
     if (ls.conflicts > 10000 && ls.lbdq_n == MS_LBDQ && (double)w.trail_n > 1.4 * ls.trail_avg) {
         ls.lbdq_n = 0; ls.lbdq_i = 0; ls.lbdq_sum = 0;
+    }
+    if (ls.rephase) {   // the assignment before the last decision was a conflict-free fixpoint: remember the longest
+        const int lim = uni(WK_PTR(int32_t, w, L, trail_lim)[w.n_levels - 1]);
+        if (lim > ls.best_trail) {
+            ls.best_trail = lim;
+            uint8_t* best = WK_PTR(uint8_t, w, L, best);
+            for (int i = w.lane; i < lim; i += MS_WAVE) {
+                const int l = WKA(int32_t, trail)[i];
+                best[l >> 1] = (uint8_t)(l & 1);
+            }
+        }
     }
     Learnt lr = analyze<LV>(w, sh, L, (uint32_t)(ls.conflicts & 0x3fffu));
     PROF_MARK(PF_ANALYZE);
@@ -1450,6 +1467,17 @@ DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         ls.lbdq_n = 0; ls.lbdq_i = 0; ls.lbdq_sum = 0;
         ls.restarts++;
         cancel_until<LV>(w, sh, L, 0);
+        if (ls.rephase && ls.conflicts >= ls.next_rephase) {
+            const uint8_t* best = WK_PTR(uint8_t, w, L, best);
+            for (uint32_t v = (uint32_t)w.lane; v < sh.n_vars; v += MS_WAVE) {
+                const uint8_t b = best[v];
+                if (b != 255) VREC[v].phase = b;
+            }
+            ls.n_rephase++;
+            ls.next_rephase = ls.conflicts + 2000ull * (ls.n_rephase + 1);
+            ls.best_trail = 0;      // the next era records its own best
+            wave_fence();
+        }
     }
     if (ls.conflicts >= ls.next_reduce || w.n_learnts > L.learnt_cap - L.learnt_cap / 8 ||
         w.lc_lits_n > L.learnt_lit_cap - L.learnt_lit_cap / 8) {
@@ -1545,6 +1573,8 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     ls.share_slots = prm.share_slots; ls.share_max_lbd = prm.share_max_lbd; ls.share_interval = prm.share_interval;
     ls.share_max_len = prm.share_max_len < MS_SHARE_MAXLEN ? prm.share_max_len : MS_SHARE_MAXLEN;
     ls.exp_n = st->exp_n; ls.wid = wid;
+    ls.best_trail = st->best_trail; ls.n_rephase = st->n_rephase; ls.next_rephase = st->next_rephase;
+    ls.rephase = prm.rephase > 0 || (prm.rephase == 0 && (wid & 1u));
     const int n_assumps_reg = ls.n_assumps;
     MsShared sc = sh;     // private copies for the cold calls (their address is taken)
     MsLayout lc = L;
@@ -1619,6 +1649,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
         st->share_pos = ls.share_pos; st->n_exported = ls.n_exported; st->n_imported = ls.n_imported;
         st->n_imported_units = ls.n_imported_units; st->last_import_confl = ls.last_import_confl;
         st->exp_n = ls.exp_n;
+        st->best_trail = ls.best_trail; st->n_rephase = ls.n_rephase; st->next_rephase = ls.next_rephase;
     }
     wk_store<LV>(w, sh, L, __builtin_readcyclecounter() - t0);
 }

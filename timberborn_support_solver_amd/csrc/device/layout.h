@@ -104,6 +104,7 @@ struct MsLayout {
                           //        assignment of a worker is 24 KB at 64x64, so all workers' fit in L2 + Infinity Cache
     uint64_t vrec;        // MsVarRec [n_vars]  level, reason (+ its literal range), saved phase, seen mark
     uint64_t vm_pos;      // int32  [n_vars]  position of the variable's live entry in vm_order
+    uint64_t best;        // uint8  [n_vars]  polarity of the variable in the longest conflict-free assignment seen (255: none)
     uint64_t trail;       // int32  [n_vars]
     uint64_t trail_lim;   // int32  [n_vars+1]
     uint64_t vm_order;    // int32  [vm_cap]   move-to-front queue as an append-only array
@@ -158,6 +159,9 @@ struct MsState {
     uint64_t share_pos;        // records of the global ring this worker has looked at
     uint64_t n_exported, n_imported, n_imported_units;
     uint64_t last_import_confl;
+    // best-phase rephasing
+    int32_t best_trail; uint32_t n_rephase;
+    uint64_t next_rephase;
 };
 
 // Launch parameters of one slice.
@@ -183,4 +187,6 @@ struct MsParams {
     uint32_t share_max_lbd;        // clauses with lbd <= this (or size <= 2) and size <= share_max_len are exported
     uint32_t share_interval;       // a worker with unseen records restarts to import them after this many conflicts
     uint32_t share_max_len;
+    int32_t rephase;               // 0: workers with an odd index rephase to their best assignment, 1: all, -1: none
+    int32_t pad3;
 };

@@ -664,6 +664,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     place(L.val, 4 * (((size_t)nv + 15) / 16));
     place(L.vrec, sizeof(MsVarRec) * (size_t)nv);
     place(L.vm_pos, 4 * (size_t)nv);
+    place(L.best, (size_t)nv);
     place(L.trail, 4 * (size_t)nv);
     place(L.trail_lim, 4 * ((size_t)nv + 1));
     place(L.vm_order, 4 * (size_t)L.vm_cap);
@@ -697,6 +698,8 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     st->pool_top = (uint32_t)pool_need;
     s.pool_init = pool_need;
     st->next_reduce = s.opts.reduce_first > 0 ? (uint64_t)s.opts.reduce_first : 2000;
+    st->next_rephase = 2000;
+    memset(T + L.best, 255, nv);
     uint32_t* val = (uint32_t*)(T + L.val);      // zero = every variable unassigned
     MsVarRec* vrec = (MsVarRec*)(T + L.vrec);
     int32_t* vm_order = (int32_t*)(T + L.vm_order);
@@ -1176,6 +1179,7 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     prm.proof_cap = s.proof_cap;
     prm.reduce_first = s.opts.reduce_first > 0 ? (uint32_t)s.opts.reduce_first : 2000u;
     prm.reduce_inc = s.opts.reduce_inc > 0 ? (uint32_t)s.opts.reduce_inc : 300u;
+    prm.rephase = s.opts.rephase;
     const bool share = mode == 0 && s.share_slots != 0;
     const uint32_t share_intake_cap = (uint32_t)std::max(16, slice_ms > 0 ? 16 * slice_ms : 256);   // 16 clauses per ms of slice
     if (share) {
