@@ -1574,7 +1574,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     ls.share_max_len = prm.share_max_len < MS_SHARE_MAXLEN ? prm.share_max_len : MS_SHARE_MAXLEN;
     ls.exp_n = st->exp_n; ls.wid = wid;
     ls.best_trail = st->best_trail; ls.n_rephase = st->n_rephase; ls.next_rephase = st->next_rephase;
-    ls.rephase = prm.rephase > 0 || (prm.rephase == 0 && (wid & 1u));
+    ls.rephase = prm.rephase == 1 || (prm.rephase == 2 && (wid & 1u));
     const int n_assumps_reg = ls.n_assumps;
     MsShared sc = sh;     // private copies for the cold calls (their address is taken)
     MsLayout lc = L;

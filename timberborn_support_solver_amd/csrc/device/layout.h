@@ -187,6 +187,6 @@ struct MsParams {
     uint32_t share_max_lbd;        // clauses with lbd <= this (or size <= 2) and size <= share_max_len are exported
     uint32_t share_interval;       // a worker with unseen records restarts to import them after this many conflicts
     uint32_t share_max_len;
-    int32_t rephase;               // 0: workers with an odd index rephase to their best assignment, 1: all, -1: none
+    int32_t rephase;               // 0: off, 1: every worker rephases to its best assignment, 2: workers with an odd index
     int32_t pad3;
 };
