@@ -475,3 +475,29 @@ def test_simplification_before_search_keeps_verdicts_and_models(terrain, pset, k
         if r == SolverResult.Sat:
             check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
         s.close()
+
+
+@pytest.mark.parametrize("terrain,k", [("rect32x32", 120), ("rect64x64", 450)])
+def test_large_terrains_with_1x1_supports_only(terrain, k):
+    """README semantics (1x1 supports only, README.md:5,29) at BASELINE's larger sizes: configs[2]'s START_COUNT = 120
+    on rect 32x32 and a loose bound on rect 64x64 are satisfiable; models self-certify (every clause, layout valid by
+    product and oracle validators, count <= k), and the 1x1-only BCP fixpoints equal the oracle's."""
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+    s = Mi355Sat()
+    s.add_cnf(cnf.lits, cnf.offsets)
+    assert solve_within(s, HARD_RUNG_LIMIT_S) == SolverResult.Sat
+    lay = check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+    assert all((w, h) == (1, 1) for _, _, w, h, _ in lay.platforms())
+    s.close()
+    scripts = [[]] + [scripted_decisions(enc, grid, seed, 40, p_positive=0.3) for seed in range(1, 6)]
+    s = Mi355Sat()
+    s.add_cnf(cnf.lits, cnf.offsets)
+    confl, vals, tl = s.propagate_batch(scripts, n_vars=cnf.n_vars)
+    for i, dec in enumerate(scripts):
+        c, v, n, _ = ora.bcp(cnf.lits, cnf.offsets, cnf.n_vars, dec)
+        assert c == confl[i]
+        if not c:
+            assert n == tl[i] and np.array_equal(v, vals[i])
+    s.close()
