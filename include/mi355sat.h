@@ -237,9 +237,9 @@ int mi355sat_debug_share_ring(mi355sat* s, int32_t* out, uint64_t cap_words, uin
 /* Optional DRUP proof (text, DIMACS literals, one lemma per line, the empty clause last) of the next plain
  * solve(), in its default configuration: all workers, clause exchange on.  Order of the lines: what the
  * simplification derived, then after every kernel slice the clauses each worker learnt in it; every line is a
- * RUP consequence of the lines before it (the exchange only hands on clauses of earlier slices).  No deletion
- * lines: a clause one worker drops may still be held by another.  Must be called before solve(); path NULL
- * disables. */
+ * RUP consequence of the lines before it (the exchange only hands on clauses of earlier slices).  Deletion lines
+ * ("d ...") are written for the clauses a worker drops when it reduces its clause database - except those another
+ * worker may hold a copy of (exchanged or imported ones).  Must be called before solve(); path NULL disables. */
 int mi355sat_set_proof_path(mi355sat* s, const char* path);
 
 #ifdef __cplusplus

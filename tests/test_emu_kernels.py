@@ -176,6 +176,22 @@ def test_emulated_unsat_verdicts_carry_a_drup_proof(tmp_path):
         l2, o2, nv2 = read_dimacs(path)
         assert nv2 == cnf.n_vars and np.array_equal(l2, cnf.lits) and np.array_equal(o2, cnf.offsets)
     assert exchanged > 0      # the proofs above include derivations that used other workers' clauses
+    # deletion lines: a worker that reduces its clause database logs "d ..." for the dropped clauses nobody else can hold
+    # (never exchanged, never imported); the checker deletes them and must still accept the proof
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 3}))
+    proof = str(tmp_path / "d.drup")
+    s = emu_solver(workers=3, slice_conflicts=16, reduce_first=25, reduce_inc=10)
+    s.set_proof_path(proof)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    assert s.solve() == SolverResult.Unsat
+    assert s.stats()["reduce_dbs"] > 0
+    s.close()
+    n_del = sum(1 for line in open(proof) if line.startswith("d "))
+    assert n_del > 0
+    assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof)) == 1
+    assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof, deletions=False)) == 1
 
 
 def test_emulated_weight_loop_like_the_gui():

@@ -1100,12 +1100,19 @@ DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
     wave_fence();
 }
 
+struct LoopState;
+// lc_lbd word of a learnt clause: LBD | MS_LBD_NOLOG (another worker may hold a copy: exchanged or imported - its deletion
+// is not logged in the proof) | used << 31
+#define MS_LBD_MASK 0x3fffffffu
+#define MS_LBD_NOLOG 0x40000000u
+DEV void proof_log_deletions(Wk& w, const MsLayout& L, LoopState* pls, bool dl, uint32_t o0, uint32_t len);
+
 // ---- learnt clause database reduction ---------------------------------------
 // Keep every clause with lbd <= 2, every locked clause and every clause used
 // since the last reduction with lbd <= 6; of the rest drop the worse half by an
 // LBD cut-off (histogram in LDS, no sort), breaking ties by age.
 template <bool LV>
-DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
+DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L, LoopState* pls = nullptr) {
     volatile uint32_t* hist = w.hist;
     MsClauseRec* lrec = WKA(MsClauseRec, wl) + sh.n_orig;   // records of the learnt clauses
     uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
@@ -1115,7 +1122,7 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
     hist[w.lane] = 0;
     lds_fence();
     for (uint32_t k = (uint32_t)w.lane; k < n; k += MS_WAVE) {
-        uint32_t l = lc_lbd[k] & 0x7fffffffu;
+        uint32_t l = lc_lbd[k] & MS_LBD_MASK;
         atomicAdd((uint32_t*)&hist[l > 63 ? 63 : l], 1u);
     }
     lds_fence();
@@ -1135,12 +1142,12 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
         uint32_t k = k0 + (uint32_t)w.lane;
         bool act = k < n;
         bool del = false;
-        uint32_t lb = 0, o0 = 0, o1 = 0;
+        uint32_t lb = 0, o0 = 0, o1 = 0, raw = 0;
         int2 ww = make_int2(0, 0);
         bool at_cut = false;
         if (act) {
-            uint32_t raw = lc_lbd[k];
-            lb = raw & 0x7fffffffu;
+            raw = lc_lbd[k];
+            lb = raw & MS_LBD_MASK;
             bool used = raw >> 31;
             const MsClauseRec ch = lrec[k];
             o0 = ch.start;
@@ -1161,6 +1168,8 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
             if (r < quota) del = true;
         }
         cut_seen += (uint32_t)popc64(cm);
+        // DRUP: deletion lines for the dropped clauses nobody else can hold (before this chunk's literals move)
+        if (pls) proof_log_deletions(w, L, pls, act && del && !(raw & MS_LBD_NOLOG), o0, o1 - o0);
         bool keep = act && !del;
         u64 km = ballot(keep);
         uint32_t nkeep = (uint32_t)popc64(km);
@@ -1191,7 +1200,7 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
         }
         if (keep) {
             lrec[nkk] = MsClauseRec{ww.x, ww.y, nlits + pre, len};
-            lc_lbd[nkk] = lb;  // clears the used bit
+            lc_lbd[nkk] = lb | (raw & MS_LBD_NOLOG);  // clears the used bit
         }
         nk += nkeep;
         nlits += total;
@@ -1217,9 +1226,9 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L) {
 
 // Store the clause in learnt_buf[0..n) and attach it.  Returns its cref (or -1).
 template <bool LV>
-DEV int add_learnt(Wk& w, const MsShared& sh, const MsLayout& L, int n, uint32_t lbd) {
+DEV int add_learnt(Wk& w, const MsShared& sh, const MsLayout& L, int n, uint32_t lbd, LoopState* pls = nullptr) {
     if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n + 8 > L.learnt_lit_cap) {
-        reduce_db<LV>(w, sh, L);  // store full before the scheduled reduction: reduce now (state is consistent here)
+        reduce_db<LV>(w, sh, L, pls);  // store full before the scheduled reduction: reduce now (state is consistent here)
         if (w.status != MS_ST_RUNNING) return -1;
         if (w.n_learnts >= L.learnt_cap || w.lc_lits_n + (uint32_t)n + 8 > L.learnt_lit_cap) {
             w.status = MS_ST_ERR_LEARNT;
@@ -1338,6 +1347,28 @@ struct LoopState {
     bool rephase;
 };
 
+// DRUP deletion lines (-2, literals, -1) for the lanes' dropped clauses, appended to the worker's log.
+DEV void proof_log_deletions(Wk& w, const MsLayout& L, LoopState* pls, bool dl, uint32_t o0, uint32_t len) {
+    if (!pls->proof_buf || ballot(dl) == 0) return;
+    const uint32_t need = dl ? len + 2 : 0;
+    uint32_t incl = need;
+    for (int o = 1; o < MS_WAVE; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (w.lane >= o) incl += t;
+    }
+    const uint32_t total = (uint32_t)bcast((int)incl, 63), base = (uint32_t)uni((int)*pls->proof_len);
+    if (base + total <= pls->proof_cap && dl) {
+        int32_t* out = pls->proof_buf + base + (incl - need);
+        const int32_t* lits = WK_PTR(int32_t, w, L, lc_lits) + o0;
+        out[0] = -2;
+        for (uint32_t j = 0; j < len; j++) out[1 + j] = lits[j];
+        out[1 + len] = -1;
+    }
+    wave_fence();
+    if (w.lane == 0) *pls->proof_len = base + total;
+    wave_fence();
+}
+
 // Attach the records of the global ring this worker has not seen yet.  Called at decision level 0
 // with the trail at its fixpoint.  Every record is a consequence of the formula alone (learnt clauses
 // never depend on assumptions: those are decisions), so it may be added to any worker of any instance
@@ -1371,7 +1402,7 @@ DEV void import_shared(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& 
             if ((free_m >> w.lane) & 1) learnt_buf[popc64(free_m & lanemask_lt(w.lane))] = word;
             wave_fence();
             // glue <= 2 would pin it for ever; an imported clause has to earn that here
-            if (add_learnt<LV>(w, sh, L, cnt, (uint32_t)(rl < 3 ? 3 : rl)) < 0) break;
+            if (add_learnt<LV>(w, sh, L, cnt, (uint32_t)(rl < 3 ? 3 : rl) | MS_LBD_NOLOG, &ls) < 0) break;
         }
         ls.n_imported++;
     }
@@ -1419,7 +1450,9 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
 #ifndef MS_SHARE_SMALL
 #define MS_SHARE_SMALL 2     // clauses up to this size are exchanged whatever their LBD
 #endif
+    bool exported = false;
     if (ls.share_pool && lr.n <= (int)ls.share_max_len && (lr.n <= MS_SHARE_SMALL || lr.lbd <= ls.share_max_lbd) && ls.exp_n < MS_EXPORT_RECS) {
+        exported = true;
         int32_t* rec = WK_PTR(int32_t, w, L, exp) + ls.exp_n * MS_SHARE_REC;
         if (w.lane <= lr.n)
             rec[w.lane] = w.lane == 0 ? (int)((uint32_t)lr.n | ((lr.lbd > 255u ? 255u : lr.lbd) << 6) | (ls.wid << 14))
@@ -1433,7 +1466,7 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         if (lit_value<LV>(w, sh, L, l0) == MS_VAL_FALSE) { w.status = MS_ST_UNSAT; return false; }
         enqueue_uniform<LV>(w, sh, L, l0, MS_REASON_NONE);
     } else {
-        int cref = add_learnt<LV>(w, sh, L, lr.n, lr.lbd);
+        int cref = add_learnt<LV>(w, sh, L, lr.n, lr.lbd | (exported ? MS_LBD_NOLOG : 0u), &ls);
         if (cref < 0) return false;
         const MsClauseHdr lh = clause_hdr_of(w, sh, L, cref);
         enqueue_uniform<LV>(w, sh, L, uni(learnt_buf[0]), cref, (uint32_t)uni((int)lh.start), (uint32_t)uni((int)lh.size));
@@ -1483,7 +1516,7 @@ DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         w.lc_lits_n > L.learnt_lit_cap - L.learnt_lit_cap / 8) {
         ls.reduce_dbs++;
         ls.next_reduce = ls.conflicts + reduce_first + (u64)reduce_inc * ls.reduce_dbs;
-        reduce_db<LV>(w, sh, L);
+        reduce_db<LV>(w, sh, L, &ls);
     }
     if (w.pool_top > L.pool_cap - L.pool_cap / 4) rebuild_watches(w, sh, L);  // pool running low: collect holes
     PROF_MARK(PF_REDUCE);

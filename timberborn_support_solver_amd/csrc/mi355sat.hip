@@ -1272,7 +1272,8 @@ void proof_drain(mi355sat& s) {
         buf.resize(len[w]);
         HIPCHK(hipMemcpy(buf.data(), s.d_proof.p + (size_t)w * s.proof_cap, sizeof(int32_t) * len[w], hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < len[w]; i++) {
-            if (buf[i] < 0) fputs("0\n", s.proof_file);
+            if (buf[i] == -2) fputs("d ", s.proof_file);       // deletion line
+            else if (buf[i] < 0) fputs("0\n", s.proof_file);
             else fprintf(s.proof_file, "%d ", (buf[i] & 1) ? -((int)inv[buf[i] >> 1] + 1) : ((int)inv[buf[i] >> 1] + 1));
         }
     }

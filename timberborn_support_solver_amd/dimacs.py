@@ -33,13 +33,16 @@ def read_dimacs(path):
     return np.asarray(lits, dtype=np.int32), np.asarray(offsets, dtype=np.uint64), n_vars
 
 
-def read_drup(path):
-    """DRUP text -> flat int32 array, clauses 0-terminated (the form a forward RUP checker takes)."""
+def read_drup(path, deletions=True):
+    """DRUP text -> flat int32 array, clauses 0-terminated (the form a forward RUP checker takes); a deletion line
+    ("d ...") becomes INT32_MIN followed by the clause, or is skipped with deletions=False."""
     out = []
     with open(path) as f:
         for line in f:
             toks = line.split()
             if toks and toks[0] == "d":
-                continue            # deletions are optional information
+                if deletions:
+                    out += [-2 ** 31] + [int(t) for t in toks[1:]]
+                continue
             out += [int(t) for t in toks]
-    return np.asarray(out, dtype=np.int32)
+    return np.asarray(out, dtype=np.int64).astype(np.int32)
