@@ -101,6 +101,9 @@ typedef struct mi355sat_opts {
                                   has seen become its saved phases every 2000, 4000, 6000, ... conflicts, at a restart):
                                   0 = default: off (measured on rect 28x28 k = 12, a hard satisfiable bound: 4.3-6.3 s without,
                                   5.4-7.5 s with), 1 = every worker, 2 = every second worker */
+    int32_t restart_k_pct;     /* Glucose's restart factor K in percent (restart when the LBD average of the last 50 conflicts times
+                                  K exceeds the global average); 0 = 80 */
+    int32_t restart_k2_pct;    /* > 0: every second worker uses this K instead (a portfolio of restart policies); 0 = same K */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
 } mi355sat_opts;

@@ -1345,6 +1345,7 @@ struct LoopState {
     uint32_t n_rephase;
     u64 next_rephase;
     bool rephase;
+    double restart_k;          // Glucose's K: restart when the recent LBD average times K exceeds the global one
 };
 
 // DRUP deletion lines (-2, literals, -1) for the lanes' dropped clauses, appended to the worker's log.
@@ -1482,7 +1483,7 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     ls.lbdq_i = (ls.lbdq_i + 1) % MS_LBDQ;
     ls.lbd_total += lr.lbd;
     const bool restart_due = ls.lbdq_n == MS_LBDQ &&
-                             ((double)ls.lbdq_sum / MS_LBDQ) * 0.8 > (double)ls.lbd_total / (double)ls.conflicts;
+                             ((double)ls.lbdq_sum / MS_LBDQ) * ls.restart_k > (double)ls.lbd_total / (double)ls.conflicts;
     const bool reduce_due = ls.conflicts >= ls.next_reduce || w.n_learnts > L.learnt_cap - L.learnt_cap / 8 ||
                             w.lc_lits_n > L.learnt_lit_cap - L.learnt_lit_cap / 8;
     const bool import_due = ls.share_pool && ls.share_n > ls.share_pos && ls.conflicts - ls.last_import_confl >= ls.share_interval;
@@ -1496,7 +1497,7 @@ template <bool LV>
 DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls, uint32_t reduce_first,
                           uint32_t reduce_inc) {
     PROF_DECL
-    if (ls.lbdq_n == MS_LBDQ && ((double)ls.lbdq_sum / MS_LBDQ) * 0.8 > (double)ls.lbd_total / (double)ls.conflicts) {
+    if (ls.lbdq_n == MS_LBDQ && ((double)ls.lbdq_sum / MS_LBDQ) * ls.restart_k > (double)ls.lbd_total / (double)ls.conflicts) {
         ls.lbdq_n = 0; ls.lbdq_i = 0; ls.lbdq_sum = 0;
         ls.restarts++;
         cancel_until<LV>(w, sh, L, 0);
@@ -1608,6 +1609,8 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     ls.exp_n = st->exp_n; ls.wid = wid;
     ls.best_trail = st->best_trail; ls.n_rephase = st->n_rephase; ls.next_rephase = st->next_rephase;
     ls.rephase = prm.rephase == 1 || (prm.rephase == 2 && (wid & 1u));
+    // restart_k2_pct: every second worker uses this K instead (a portfolio of restart policies)
+    ls.restart_k = 0.01 * (double)(((wid & 1u) && prm.restart_k2_pct > 0) ? prm.restart_k2_pct : (prm.restart_k_pct > 0 ? prm.restart_k_pct : 80));
     const int n_assumps_reg = ls.n_assumps;
     MsShared sc = sh;     // private copies for the cold calls (their address is taken)
     MsLayout lc = L;

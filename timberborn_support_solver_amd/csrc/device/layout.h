@@ -188,5 +188,6 @@ struct MsParams {
     uint32_t share_interval;       // a worker with unseen records restarts to import them after this many conflicts
     uint32_t share_max_len;
     int32_t rephase;               // 0: off, 1: every worker rephases to its best assignment, 2: workers with an odd index
-    int32_t pad3;
+    int32_t restart_k_pct;         // Glucose restart factor K in percent (0 = 80)
+    int32_t restart_k2_pct, pad4;  // > 0: workers with an odd index use this K
 };

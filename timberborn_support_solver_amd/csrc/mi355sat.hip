@@ -1180,6 +1180,8 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     prm.reduce_first = s.opts.reduce_first > 0 ? (uint32_t)s.opts.reduce_first : 2000u;
     prm.reduce_inc = s.opts.reduce_inc > 0 ? (uint32_t)s.opts.reduce_inc : 300u;
     prm.rephase = s.opts.rephase;
+    prm.restart_k_pct = s.opts.restart_k_pct;
+    prm.restart_k2_pct = s.opts.restart_k2_pct;
     const bool share = mode == 0 && s.share_slots != 0;
     const uint32_t share_intake_cap = (uint32_t)std::max(16, slice_ms > 0 ? 16 * slice_ms : 256);   // 16 clauses per ms of slice
     if (share) {
