@@ -1,5 +1,5 @@
 // tbs_cli — minimal command-line driver of the solve path (NOT the reference's REPL/UI):
-//   tbs_cli rect W H [-l1:K] [--platforms default|1x1] [--workers N] [--sweep]
+//   tbs_cli rect W H [-l1:K] [--platforms default|1x1] [--workers N] [--sweep] [--gpu N] [--seed N] [--verbose] [--no-simp]
 //   tbs_cli file PATH.toml [-l1:K] ...
 // Mirrors `solve -l<dims>:<n>` of crates/repl/src/main.rs:44-75,248-261: encode once, then solver_loop.
 // Ctrl-C calls mi355sat_interrupt (main.rs:297-324).
@@ -23,7 +23,8 @@ int main(int argc, char** argv) {
     using namespace tbs;
     try {
         if (argc < 3) {
-            fprintf(stderr, "usage: %s rect W H | file PATH [-l<dims>:<n>]... [--platforms default|1x1] [--workers N] [--sweep]\n", argv[0]);
+            fprintf(stderr, "usage: %s rect W H | file PATH [-l<dims>:<n>]... [--platforms default|1x1] [--workers N] [--sweep] [--gpu N] [--seed N] "
+                            "[--verbose] [--no-simp]\n", argv[0]);
             return 2;
         }
         WorldGrid grid;
@@ -50,7 +51,11 @@ int main(int argc, char** argv) {
             } else if (arg == "--platforms" && a + 1 < argc) {
                 if (!strcmp(argv[++a], "1x1")) defs = {Dims{1, 1}};
             } else if (arg == "--workers" && a + 1 < argc) opts.workers = atoi(argv[++a]);
-            else if (arg == "--sweep") sweep = true;   // all bounds k0..0 as one batch on the device
+            else if (arg == "--gpu" && a + 1 < argc) opts.device = atoi(argv[++a]);          // HIP device ordinal (one process per GPU)
+            else if (arg == "--seed" && a + 1 < argc) opts.seed = strtoull(argv[++a], nullptr, 10);   // diversification seed
+            else if (arg == "--verbose") opts.verbose = 1;
+            else if (arg == "--no-simp") opts.simp = -1;
+            else if (arg == "--sweep") sweep = true;   // the bounds below the first one as one batch on the device
             else throw std::runtime_error("unknown argument " + arg);
         }
         Encoding enc = Encoding::encode(defs, grid);
