@@ -1206,7 +1206,8 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     if (mode == 0) {
         // the build compiled for the launch's waves per SIMD: 1 (<= 1024 workers: the SIMD's whole register file, everything
         // inlined), 2 (<= 2048: no spills either), else the full fleet's
-        const int wps = s.opts.one_per_simd < 0 ? MS_SEARCH_WAVES_PER_SIMD : (active <= 1024 ? 1 : (active <= 2048 ? 2 : MS_SEARCH_WAVES_PER_SIMD));
+        int wps = s.opts.one_per_simd < 0 ? MS_SEARCH_WAVES_PER_SIMD : (active <= 1024 ? 1 : (active <= 2048 ? 2 : MS_SEARCH_WAVES_PER_SIMD));
+        if (s.opts.one_per_simd == 2 || s.opts.one_per_simd == 4) wps = std::max(wps, s.opts.one_per_simd == 2 ? 2 : MS_SEARCH_WAVES_PER_SIMD);   // (A/B: a build for more waves)
 #define MS_LAUNCH_SEARCH(LVV, W) hipLaunchKernelGGL((ms_search_kernel<LVV, W>), dim3(active), dim3(MS_WAVE), (LVV) ? dyn : 0, s.stream, s.sh, s.L, s.d_slabs.p, prm)
         if (lds) {
             if (wps == 1) MS_LAUNCH_SEARCH(true, 1);
