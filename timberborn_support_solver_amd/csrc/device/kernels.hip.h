@@ -1370,6 +1370,29 @@ DEV void proof_log_deletions(Wk& w, const MsLayout& L, LoopState* pls, bool dl, 
     wave_fence();
 }
 
+// Every field of LoopState is wave-uniform; after a load from the caller's scratch copy the compiler cannot know that.
+DEV void ls_uniformize(LoopState& ls) {
+    ls.conflicts = uni64(ls.conflicts); ls.restarts = uni64(ls.restarts); ls.reduce_dbs = uni64(ls.reduce_dbs);
+    ls.lbdq_sum = uni64(ls.lbdq_sum); ls.lbd_total = uni64(ls.lbd_total); ls.next_reduce = uni64(ls.next_reduce);
+    ls.learnt_total = uni64(ls.learnt_total); ls.learnt_lits_total = uni64(ls.learnt_lits_total);
+    ls.lbdq_n = (uint32_t)uni((int)ls.lbdq_n); ls.lbdq_i = (uint32_t)uni((int)ls.lbdq_i);
+    ls.trail_avg = __longlong_as_double((long long)uni64((u64)__double_as_longlong(ls.trail_avg)));
+    ls.n_assumps = uni(ls.n_assumps);
+    ls.lbdq = (volatile uint32_t*)uni64((u64)ls.lbdq);
+    ls.proof_buf = (int32_t*)uni64((u64)ls.proof_buf); ls.proof_len = (uint32_t*)uni64((u64)ls.proof_len);
+    ls.proof_cap = (uint32_t)uni((int)ls.proof_cap);
+    ls.share_pool = (const int4*)uni64((u64)ls.share_pool);
+    ls.share_n = uni64(ls.share_n); ls.share_pos = uni64(ls.share_pos); ls.n_exported = uni64(ls.n_exported);
+    ls.n_imported = uni64(ls.n_imported); ls.n_imported_units = uni64(ls.n_imported_units);
+    ls.last_import_confl = uni64(ls.last_import_confl);
+    ls.share_slots = (uint32_t)uni((int)ls.share_slots); ls.share_max_lbd = (uint32_t)uni((int)ls.share_max_lbd);
+    ls.share_max_len = (uint32_t)uni((int)ls.share_max_len); ls.share_interval = (uint32_t)uni((int)ls.share_interval);
+    ls.exp_n = (uint32_t)uni((int)ls.exp_n); ls.wid = (uint32_t)uni((int)ls.wid);
+    ls.best_trail = uni(ls.best_trail); ls.n_rephase = (uint32_t)uni((int)ls.n_rephase); ls.next_rephase = uni64(ls.next_rephase);
+    ls.rephase = uni((int)ls.rephase) != 0;
+    ls.restart_k = __longlong_as_double((long long)uni64((u64)__double_as_longlong(ls.restart_k)));
+}
+
 // Attach the records of the global ring this worker has not seen yet.  Called at decision level 0
 // with the trail at its fixpoint.  Every record is a consequence of the formula alone (learnt clauses
 // never depend on assumptions: those are decisions), so it may be added to any worker of any instance
@@ -1513,6 +1536,7 @@ DEV_COLD bool on_conflict(Wk& wr, const MsShared& shr, const MsLayout& Lr, LoopS
     Wk w = wr;
     wk_uniformize(w);
     LoopState ls = lsr;
+    ls_uniformize(ls);
     const bool r = on_conflict_body<LV>(w, sh, L, ls);
     wr = w;
     lsr = ls;
@@ -1583,6 +1607,7 @@ DEV_COLD void on_fixpoint(Wk& wr, const MsShared& shr, const MsLayout& Lr, LoopS
     Wk w = wr;
     wk_uniformize(w);
     LoopState ls = lsr;
+    ls_uniformize(ls);
     on_fixpoint_body<LV>(w, sh, L, ls, reduce_first, reduce_inc);
     wr = w;
     lsr = ls;
@@ -1651,7 +1676,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     MsLayout lc = L;
     const MsKernarg ka = MS_KERNARG();
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (WPS == 2) {   // the 2-waves build reads sh / L through the argument segment: make sure they are where it looks
+    if (WPS != 1) {   // the called builds read sh / L through the argument segment: make sure they are where it looks
         const MsShared& s2 = *(const MsShared*)ka;
         const MsLayout& l2 = *(const MsLayout*)(ka + ((sizeof(MsShared) + 7) & ~7ul));
         if (s2.n_vars != sh.n_vars || s2.cl_lits != sh.cl_lits || l2.slab_bytes != L.slab_bytes || l2.pool != L.pool || l2.n_vars != L.n_vars) {
@@ -1674,7 +1699,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
             if (ONE) maintenance_due = on_conflict_body<LV>(w, sh, L, ls);
             else {
                 Wk t = w;
-                maintenance_due = on_conflict<LV, WPS == 2>(t, sc, lc, ls, ka);
+                maintenance_due = on_conflict<LV, true>(t, sc, lc, ls, ka);
                 w = t;
                 wk_uniformize(w);
             }
@@ -1693,7 +1718,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
                 if (ONE) on_fixpoint_body<LV>(w, sh, L, ls, prm.reduce_first, prm.reduce_inc);
                 else {
                     Wk t = w;
-                    on_fixpoint<LV, WPS == 2>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc, ka);
+                    on_fixpoint<LV, true>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc, ka);
                     w = t;
                     wk_uniformize(w);
                 }
