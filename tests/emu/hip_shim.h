@@ -65,6 +65,8 @@ static inline unsigned long long __ballot(int p) {
 }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline long long __double_as_longlong(double d) { long long x; __builtin_memcpy(&x, &d, 8); return x; }
+static inline double __longlong_as_double(long long x) { double d; __builtin_memcpy(&d, &x, 8); return d; }
 static inline int __shfl(int v, int src, int /*w*/ = 64) {
     emu::collective_begin((uint64_t)(uint32_t)v, 2);
     return (int)(uint32_t)emu::collective_read(src & 63);
