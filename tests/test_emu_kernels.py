@@ -472,3 +472,20 @@ def test_emulated_sweep_priorities_and_reopening_keep_the_answers():
         if res[i] == SolverResult.Sat:
             check_sat_answer(cnf, s.solution_of(i, cnf.n_vars), enc, grid, k)
     s.close()
+
+
+@pytest.mark.parametrize("one_per_simd", [2, 4], ids=["two-waves-build", "full-fleet-build"])
+def test_emulated_called_builds_of_the_search_kernel(one_per_simd):
+    """The search kernel exists in three builds (waves per SIMD 1 / 2 / 4).  Small fleets run the inlined one; this forces
+    the two CALLED builds - the per-conflict code a function that works on register copies (2) or on the caller's context
+    (4) - through the same verdict / model / exchange checks."""
+    for terrain, pset, k, want in [("ex1", "1x1", 2, "Unsat"), ("ex1", "1x1", 3, "Sat"), ("rect8x8", "1x1", 3, "Unsat")]:
+        grid = make_grid(terrain)
+        enc = Encoding.encode(platform_defs(pset), grid)
+        cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+        s = emu_solver(workers=4, slice_conflicts=10, one_per_simd=one_per_simd)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        assert s.solve().name == want
+        if want == "Sat":
+            check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+        s.close()
