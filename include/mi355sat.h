@@ -104,6 +104,8 @@ typedef struct mi355sat_opts {
     int32_t restart_k_pct;     /* Glucose's restart factor K in percent (restart when the LBD average of the last 50 conflicts times
                                   K exceeds the global average); 0 = 80 */
     int32_t restart_k2_pct;    /* > 0: every second worker uses this K instead (a portfolio of restart policies); 0 = same K */
+    int32_t import_pct;        /* share (percent) of the exchanged clauses of 3 and more literals each worker attaches (every worker
+                                  another share; units and binaries always); 0 = 100 */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
 } mi355sat_opts;

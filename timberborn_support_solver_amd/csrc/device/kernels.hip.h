@@ -1345,6 +1345,7 @@ struct LoopState {
     uint32_t n_rephase;
     u64 next_rephase;
     bool rephase;
+    uint32_t import_pct;
     double restart_k;          // Glucose's K: restart when the recent LBD average times K exceeds the global one
 };
 
@@ -1390,6 +1391,7 @@ DEV void ls_uniformize(LoopState& ls) {
     ls.exp_n = (uint32_t)uni((int)ls.exp_n); ls.wid = (uint32_t)uni((int)ls.wid);
     ls.best_trail = uni(ls.best_trail); ls.n_rephase = (uint32_t)uni((int)ls.n_rephase); ls.next_rephase = uni64(ls.next_rephase);
     ls.rephase = uni((int)ls.rephase) != 0;
+    ls.import_pct = (uint32_t)uni((int)ls.import_pct);
     ls.restart_k = __longlong_as_double((long long)uni64((u64)__double_as_longlong(ls.restart_k)));
 }
 
@@ -1412,6 +1414,8 @@ DEV void import_shared(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& 
         const int hdr = bcast(word, 0);
         const int rn = hdr & 63, rl = (hdr >> 6) & 255;
         if ((uint32_t)(hdr >> 14) == ls.wid || rn < 1 || rn > MS_SHARE_MAXLEN) continue;
+        // import_pct < 100: a worker attaches only that share of the clauses of 3 and more literals (each worker another one)
+        if (rn > 2 && ls.import_pct < 100 && (uint32_t)((((uint32_t)pos * 2654435761u) ^ (ls.wid * 40503u)) >> 13) % 100u >= ls.import_pct) continue;
         const bool in = w.lane >= 1 && w.lane <= rn;
         const int v = in ? lit_value<LV>(w, sh, L, word) : MS_VAL_FALSE;   // units attached before are visible
         if (ballot(in && v == MS_VAL_TRUE)) continue;
@@ -1670,6 +1674,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     ls.exp_n = st->exp_n; ls.wid = wid;
     ls.best_trail = st->best_trail; ls.n_rephase = st->n_rephase; ls.next_rephase = st->next_rephase;
     ls.rephase = prm.rephase == 1 || (prm.rephase == 2 && (wid & 1u));
+    ls.import_pct = prm.import_pct > 0 ? (uint32_t)prm.import_pct : 100u;
     // restart_k2_pct: every second worker uses this K instead (a portfolio of restart policies)
     ls.restart_k = 0.01 * (double)(((wid & 1u) && prm.restart_k2_pct > 0) ? prm.restart_k2_pct : (prm.restart_k_pct > 0 ? prm.restart_k_pct : 80));
     const int n_assumps_reg = ls.n_assumps;

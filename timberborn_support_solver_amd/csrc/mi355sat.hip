@@ -1182,6 +1182,7 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     prm.rephase = s.opts.rephase;
     prm.restart_k_pct = s.opts.restart_k_pct;
     prm.restart_k2_pct = s.opts.restart_k2_pct;
+    prm.import_pct = s.opts.import_pct;
     const bool share = mode == 0 && s.share_slots != 0;
     const uint32_t share_intake_cap = (uint32_t)std::max(16, slice_ms > 0 ? 16 * slice_ms : 256);   // 16 clauses per ms of slice
     if (share) {
