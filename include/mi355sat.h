@@ -105,7 +105,10 @@ typedef struct mi355sat_opts {
                                   K exceeds the global average); 0 = 80 */
     int32_t restart_k2_pct;    /* > 0: every second worker uses this K instead (a portfolio of restart policies); 0 = same K */
     int32_t import_pct;        /* share (percent) of the exchanged clauses of 3 and more literals each worker attaches (every worker
-                                  another share; units and binaries always); 0 = 100 */
+                                  another share; units and binaries always); 0 = default 50: a worker that attaches everything
+                                  1023 others export spends its time on their clauses (measured, 1024 workers: rect 16 1x1 k = 14
+                                  9.8-10.2 s at 50 %, 9.0-9.8 s at 25 %, 10.0-13.2 s at 100 %; rect 26 k = 10 46-56 s at 50 %,
+                                  60-72 s at 100 %; rect 28 k = 11 within the run-to-run spread) */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
 } mi355sat_opts;
