@@ -109,6 +109,9 @@ typedef struct mi355sat_opts {
                                   1023 others export spends its time on their clauses (measured, 1024 workers: rect 16 1x1 k = 14
                                   9.8-10.2 s at 50 %, 9.0-9.8 s at 25 %, 10.0-13.2 s at 100 %; rect 26 k = 10 46-56 s at 50 %,
                                   60-72 s at 100 %; rect 28 k = 11 within the run-to-run spread) */
+    int32_t vivify;            /* vivification of learnt clauses: at a restart, every 400 conflicts, up to this many recent learnt
+                                  clauses of LBD <= 6 (at most 64 literals) are re-derived literal by literal under unit
+                                  propagation and replaced by the shorter clause that implies them; 0 = off */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
 } mi355sat_opts;

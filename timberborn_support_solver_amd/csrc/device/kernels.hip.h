@@ -1103,8 +1103,9 @@ DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
 struct LoopState;
 // lc_lbd word of a learnt clause: LBD | MS_LBD_NOLOG (another worker may hold a copy: exchanged or imported - its deletion
 // is not logged in the proof) | used << 31
-#define MS_LBD_MASK 0x3fffffffu
+#define MS_LBD_MASK 0x1fffffffu
 #define MS_LBD_NOLOG 0x40000000u
+#define MS_LBD_VIVIFIED 0x20000000u   // the clause went through vivify_pass once
 DEV void proof_log_deletions(Wk& w, const MsLayout& L, LoopState* pls, bool dl, uint32_t o0, uint32_t len);
 
 // ---- learnt clause database reduction ---------------------------------------
@@ -1200,7 +1201,7 @@ DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L, LoopState* pls 
         }
         if (keep) {
             lrec[nkk] = MsClauseRec{ww.x, ww.y, nlits + pre, len};
-            lc_lbd[nkk] = lb | (raw & MS_LBD_NOLOG);  // clears the used bit
+            lc_lbd[nkk] = lb | (raw & (MS_LBD_NOLOG | MS_LBD_VIVIFIED));  // clears the used bit
         }
         nk += nkeep;
         nlits += total;
@@ -1346,6 +1347,8 @@ struct LoopState {
     u64 next_rephase;
     bool rephase;
     uint32_t import_pct;
+    uint32_t vivify;           // clauses per vivification pass (0 = off)
+    u64 next_vivify, n_vivified, n_viv_lits;
     double restart_k;          // Glucose's K: restart when the recent LBD average times K exceeds the global one
 };
 
@@ -1392,6 +1395,7 @@ DEV void ls_uniformize(LoopState& ls) {
     ls.best_trail = uni(ls.best_trail); ls.n_rephase = (uint32_t)uni((int)ls.n_rephase); ls.next_rephase = uni64(ls.next_rephase);
     ls.rephase = uni((int)ls.rephase) != 0;
     ls.import_pct = (uint32_t)uni((int)ls.import_pct);
+    ls.vivify = (uint32_t)uni((int)ls.vivify); ls.next_vivify = uni64(ls.next_vivify); ls.n_vivified = uni64(ls.n_vivified); ls.n_viv_lits = uni64(ls.n_viv_lits);
     ls.restart_k = __longlong_as_double((long long)uni64((u64)__double_as_longlong(ls.restart_k)));
 }
 
@@ -1548,6 +1552,93 @@ DEV_COLD bool on_conflict(Wk& wr, const MsShared& shr, const MsLayout& Lr, LoopS
     return r;
 }
 
+// ---- vivification of learnt clauses (Luo et al. 2017, "learnt clause minimisation"; CaDiCaL's vivify) ------------------
+// At decision level 0, for a recent learnt clause of small LBD that has not been through this yet: falsify its literals
+// one after the other (a decision + BCP each).  A literal that is already false by then is redundant; if one becomes
+// true, or BCP runs into a conflict, the literals decided so far (plus that one) already form an implied clause.  The
+// shorter clause replaces the old one in place; it is a RUP lemma (logged) and is exported like a freshly learnt clause.
+// One literal per lane, so clauses of up to 64 literals.  Returns true if a clause changed.
+template <bool LV>
+DEV bool vivify_pass(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls) {
+    MsClauseRec* lrec = WKA(MsClauseRec, wl) + sh.n_orig;
+    uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
+    int32_t* lc_lits = WK_PTR(int32_t, w, L, lc_lits);
+    bool changed = false;
+    uint32_t done = 0;
+    for (int k = (int)w.n_learnts - 1; k >= 0 && done < ls.vivify && w.status == MS_ST_RUNNING && w.qhead == w.trail_n; k--) {
+        const uint32_t raw = (uint32_t)uni((int)lc_lbd[k]);
+        if ((raw & MS_LBD_VIVIFIED) || (raw & MS_LBD_MASK) > 6u) continue;
+        const MsClauseRec cr = lrec[k];
+        const int size = uni((int)cr.size);
+        const uint32_t start = (uint32_t)uni((int)cr.start);
+        if (w.lane == 0) lc_lbd[k] = raw | MS_LBD_VIVIFIED;
+        if (size < 3 || size > MS_WAVE) continue;
+        done++;
+        const bool in = w.lane < size;
+        const int lit = in ? lc_lits[start + w.lane] : 0;
+        const int v0 = in ? lit_value<LV>(w, sh, L, lit) : MS_VAL_FALSE;
+        if (ballot(in && v0 == MS_VAL_TRUE)) continue;                  // satisfied at level 0: nothing to gain
+        const u64 alive = ballot(in && v0 == MS_VAL_UNDEF);
+        if (popc64(alive) < 2) continue;                                // (a unit or empty clause under level 0: BCP's business)
+        u64 kept = 0;
+        for (u64 m = alive; m != 0; m &= m - 1) {
+            const int i = first_lane(m);
+            const int li = bcast(lit, i);
+            const int vi = lit_value<LV>(w, sh, L, li);
+            if (vi == MS_VAL_TRUE) { kept |= 1ull << i; break; }        // implied by the negations so far
+            if (vi == MS_VAL_FALSE) continue;                           // falsified by them: redundant
+            kept |= 1ull << i;
+            if ((m & (m - 1)) == 0) break;                              // the last literal needs no decision
+            new_decision_level<LV>(w, sh, L);
+            enqueue_uniform<LV>(w, sh, L, li ^ 1, MS_REASON_NONE);
+            if (propagate<LV>(w, sh, L)) break;                         // conflict: the literals decided so far are a clause
+        }
+        cancel_until<LV>(w, sh, L, 0);
+        w.confl_kind = 0;
+        const int n_new = popc64(kept);
+        if (n_new >= size || n_new < 1) continue;
+        changed = true;
+        ls.n_vivified++;
+        ls.n_viv_lits += (u64)(size - n_new);
+        const bool mine = (kept >> w.lane) & 1ull;
+        const int rank = popc64(kept & lanemask_lt(w.lane));
+        if (ls.proof_buf) {   // DRUP: the shorter clause is a lemma
+            const uint32_t o = *ls.proof_len;
+            if (o + (uint32_t)n_new + 1 <= ls.proof_cap) {
+                if (mine) ls.proof_buf[o + rank] = lit;
+                if (w.lane == 0) ls.proof_buf[o + n_new] = -1;
+            }
+            wave_fence();
+            if (w.lane == 0) *ls.proof_len = o + (uint32_t)n_new + 1;
+            wave_fence();
+        }
+        if (n_new == 1) {     // a new level-0 fact; the old clause is satisfied by it
+            enqueue_uniform<LV>(w, sh, L, bcast(lit, first_lane(kept)), MS_REASON_NONE);
+            break;            // BCP first
+        }
+        wave_fence();
+        if (mine) lc_lits[start + rank] = lit;
+        const int w0 = bcast(lit, first_lane(kept)), w1 = bcast(lit, first_lane(kept & (kept - 1)));
+        uint32_t lbd = raw & MS_LBD_MASK;
+        if (lbd > (uint32_t)n_new - 1) lbd = (uint32_t)n_new - 1;
+        bool exported = (raw & MS_LBD_NOLOG) != 0;
+        if (!exported && ls.share_pool && n_new <= (int)ls.share_max_len && (n_new <= MS_SHARE_SMALL || lbd <= ls.share_max_lbd) && ls.exp_n < MS_EXPORT_RECS) {
+            int32_t* rec = WK_PTR(int32_t, w, L, exp) + ls.exp_n * MS_SHARE_REC;
+            if (w.lane == 0) rec[0] = (int)((uint32_t)n_new | ((lbd > 255u ? 255u : lbd) << 6) | (ls.wid << 14));
+            if (mine) rec[1 + rank] = lit;
+            ls.exp_n++;
+            ls.n_exported++;
+            exported = true;
+        }
+        if (w.lane == 0) {
+            lrec[k] = MsClauseRec{w0, w1, start, (uint32_t)n_new};
+            lc_lbd[k] = lbd | MS_LBD_VIVIFIED | (raw & 0x80000000u) | (exported ? MS_LBD_NOLOG : 0u);
+        }
+        wave_fence();
+    }
+    return changed;
+}
+
 // BCP reached a fixpoint without conflict: restart? reduce? then assumptions / next decision.
 template <bool LV>
 DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls, uint32_t reduce_first,
@@ -1568,6 +1659,11 @@ DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
             ls.best_trail = 0;      // the next era records its own best
             wave_fence();
         }
+    }
+    if (ls.vivify && w.n_levels == 0 && ls.conflicts >= ls.next_vivify) {
+        ls.next_vivify = ls.conflicts + 400;
+        if (vivify_pass<LV>(w, sh, L, ls)) rebuild_watches(w, sh, L);   // shrunk clauses watch their new first two literals
+        if (w.status != MS_ST_RUNNING || w.qhead < w.trail_n) return;   // a new unit: BCP first
     }
     if (ls.conflicts >= ls.next_reduce || w.n_learnts > L.learnt_cap - L.learnt_cap / 8 ||
         w.lc_lits_n > L.learnt_lit_cap - L.learnt_lit_cap / 8) {
@@ -1675,6 +1771,8 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     ls.best_trail = st->best_trail; ls.n_rephase = st->n_rephase; ls.next_rephase = st->next_rephase;
     ls.rephase = prm.rephase == 1 || (prm.rephase == 2 && (wid & 1u));
     ls.import_pct = prm.import_pct > 0 ? (uint32_t)prm.import_pct : 50u;
+    ls.vivify = prm.vivify > 0 ? (uint32_t)prm.vivify : 0u;
+    ls.next_vivify = st->next_vivify; ls.n_vivified = st->n_vivified; ls.n_viv_lits = st->n_viv_lits;
     // restart_k2_pct: every second worker uses this K instead (a portfolio of restart policies)
     ls.restart_k = 0.01 * (double)(((wid & 1u) && prm.restart_k2_pct > 0) ? prm.restart_k2_pct : (prm.restart_k_pct > 0 ? prm.restart_k_pct : 80));
     const int n_assumps_reg = ls.n_assumps;
@@ -1763,6 +1861,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
         st->n_imported_units = ls.n_imported_units; st->last_import_confl = ls.last_import_confl;
         st->exp_n = ls.exp_n;
         st->best_trail = ls.best_trail; st->n_rephase = ls.n_rephase; st->next_rephase = ls.next_rephase;
+        st->next_vivify = ls.next_vivify; st->n_vivified = ls.n_vivified; st->n_viv_lits = ls.n_viv_lits;
     }
     wk_store<LV>(w, sh, L, __builtin_readcyclecounter() - t0);
 }

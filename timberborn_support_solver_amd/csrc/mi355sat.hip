@@ -1183,6 +1183,7 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     prm.restart_k_pct = s.opts.restart_k_pct;
     prm.restart_k2_pct = s.opts.restart_k2_pct;
     prm.import_pct = s.opts.import_pct;
+    prm.vivify = s.opts.vivify;
     const bool share = mode == 0 && s.share_slots != 0;
     const uint32_t share_intake_cap = (uint32_t)std::max(16, slice_ms > 0 ? 16 * slice_ms : 256);   // 16 clauses per ms of slice
     if (share) {
@@ -1609,8 +1610,9 @@ int sweep_step(mi355sat& s, Sweep& sw) {
     }
     sw.conflicts = confl;
     if (s.opts.verbose) {
-        uint64_t props = 0, nl = 0, busy = 0;
-        for (auto& st : sw.sts) { props += st.propagations; nl += st.n_learnts; }
+        uint64_t props = 0, nl = 0, busy = 0, viv = 0, vivl = 0;
+        for (auto& st : sw.sts) { props += st.propagations; nl += st.n_learnts; viv += st.n_vivified; vivl += st.n_viv_lits; }
+        if (viv) fprintf(stderr, "[mi355sat] vivified %llu clauses, %llu literals removed\n", (unsigned long long)viv, (unsigned long long)vivl);
         for (auto b : sw.w_busy) busy += b;
         fprintf(stderr, "[mi355sat] slice: decided %u/%u conflicts=%llu props=%llu kernel=%.3fs busy=%llu/%u splits=%llu closed=%llu kept=%llu\n",
                 sw.decided, n_instances, (unsigned long long)confl, (unsigned long long)props, s.stats.kernel_seconds,
