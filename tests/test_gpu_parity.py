@@ -179,7 +179,9 @@ def test_unsat_verdicts_carry_a_checked_drup_proof(tmp_path, terrain, pset, k):
     # the long refutation with 16 workers: the proof holds every worker's clauses and the oracle's checker is a
     # plain occurrence-list propagator (the default fleet's log of this one takes it many minutes)
     long_one = (terrain, pset, k) == ("rect16x16", "1x1", 10)
-    s = Mi355Sat(workers=16, slice_ms=5) if long_one else Mi355Sat()
+    # ... with vivification on, so that its lemmas (learnt clauses re-derived shorter under unit propagation) are in the
+    # checked proof too
+    s = Mi355Sat(workers=16, slice_ms=5, vivify=16) if long_one else Mi355Sat()
     s.set_proof_path(proof)
     s.add_cnf(cnf.lits, cnf.offsets)
     assert s.solve() == SolverResult.Unsat
