@@ -1771,7 +1771,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     ls.best_trail = st->best_trail; ls.n_rephase = st->n_rephase; ls.next_rephase = st->next_rephase;
     ls.rephase = prm.rephase == 1 || (prm.rephase == 2 && (wid & 1u));
     ls.import_pct = prm.import_pct > 0 ? (uint32_t)prm.import_pct : 50u;
-    ls.vivify = prm.vivify > 0 ? (uint32_t)prm.vivify : 0u;
+    ls.vivify = prm.vivify > 0 ? (uint32_t)prm.vivify : (prm.vivify == 0 ? 4u : 0u);
     ls.next_vivify = st->next_vivify; ls.n_vivified = st->n_vivified; ls.n_viv_lits = st->n_viv_lits;
     // restart_k2_pct: every second worker uses this K instead (a portfolio of restart policies)
     ls.restart_k = 0.01 * (double)(((wid & 1u) && prm.restart_k2_pct > 0) ? prm.restart_k2_pct : (prm.restart_k_pct > 0 ? prm.restart_k_pct : 80));
