@@ -699,6 +699,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     s.pool_init = pool_need;
     st->next_reduce = s.opts.reduce_first > 0 ? (uint64_t)s.opts.reduce_first : 2000;
     st->next_rephase = 2000;
+    st->next_vivify = 1500;   // (easy bounds are decided before that: vivification is for the long refutations)
     memset(T + L.best, 255, nv);
     uint32_t* val = (uint32_t*)(T + L.val);      // zero = every variable unassigned
     MsVarRec* vrec = (MsVarRec*)(T + L.vrec);
