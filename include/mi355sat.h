@@ -93,8 +93,11 @@ typedef struct mi355sat_opts {
                                   -1 = always the 4-waves-per-SIMD build (A/B) */
     int32_t simp;              /* formula simplification before search (the reference's backend is `simp::Glucose`): 0 = default
                                   (on): equivalent-literal substitution, failed-literal probing on the device, subsumption and
-                                  self-subsuming resolution on the device; -1 = only level-0 unit propagation.  Invisible at this
-                                  interface: models, assumptions and proofs stay in the caller's variables. */
+                                  self-subsuming resolution on the device; 2 = the same plus bounded variable elimination
+                                  (`SimpSolver::eliminate`: grow 0, resolvents of at most 20 literals; the variables of the
+                                  assumptions are kept, eliminated ones get their values back when a model is read);
+                                  -1 = only level-0 unit propagation.  Invisible at this interface: models, assumptions and
+                                  proofs stay in the caller's variables. */
     int32_t phase_mix;         /* 0 = default: every worker starts with all saved phases FALSE (no platform anywhere);
                                   1 = portfolio of initial phases: a quarter of the workers start TRUE, a quarter at random */
     int32_t rephase;           /* rephasing to the best assignment (the polarities of the longest conflict-free assignment a worker
@@ -147,6 +150,7 @@ typedef struct mi355sat_stats_t {
     uint64_t simp_clauses_removed; /* clauses subsumed or strengthened */
     uint64_t workers;              /* search workers (wavefronts) of the last solve / batch / sweep: what was asked for, or
                                       what device memory had room for */
+    uint64_t simp_eliminated;      /* variables resolved away before search (bounded variable elimination) */
 } mi355sat_stats_t;
 
 /* --- lifecycle (Default::default / Drop) --------------------------------- */

@@ -33,7 +33,7 @@ pub struct Stats {
     pub solve_seconds: f64, pub kernel_seconds: f64, pub kernel_launches: u64, pub n_deq: u64, pub n_watch: u64,
     pub n_cl_lit: u64, pub n_move: u64, pub n_enq: u64, pub n_sat: u64, pub n_unsat: u64, pub n_terminated: u64,
     pub bcp_steps: u64, pub bcp_requeued: u64, pub shared_exported: u64, pub shared_imported: u64,
-    pub shared_imported_units: u64, pub simp_units: u64, pub simp_equivalences: u64, pub simp_clauses_removed: u64, pub workers: u64,
+    pub shared_imported_units: u64, pub simp_units: u64, pub simp_equivalences: u64, pub simp_clauses_removed: u64, pub workers: u64, pub simp_eliminated: u64,
 }
 
 extern "C" {

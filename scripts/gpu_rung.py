@@ -27,5 +27,6 @@ for cfg in cfgs:
     W = cfg.get("workers", 0)
     print(f"{cfg}: {r.name} {dt:.2f}s kernel={st['kernel_seconds']:.2f}s conflicts={st['conflicts']:.3e} "
           f"({st['conflicts']/max(st['kernel_seconds'],1e-9):.3e}/s) props={st['propagations']:.3e} learnts={st['learnts']} "
-          f"exp={st['shared_exported']} imp={st['shared_imported']} units={st['shared_imported_units']} restarts={st['restarts']}", flush=True)
+          f"exp={st['shared_exported']} imp={st['shared_imported']} units={st['shared_imported_units']} restarts={st['restarts']} "
+          f"simp: units={st['simp_units']} equiv={st['simp_equivalences']} removed={st['simp_clauses_removed']} eliminated={st['simp_eliminated']}", flush=True)
     s.close()

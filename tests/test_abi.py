@@ -54,7 +54,7 @@ def test_signature_and_opts_struct_layout():
     L.mi355sat_abi_sizes.restype = ctypes.c_uint64
     st_size = ctypes.c_uint64(0)
     assert L.mi355sat_abi_sizes(ctypes.byref(st_size)) == ctypes.sizeof(Mi355SatOpts)     # the header's structs,
-    assert st_size.value == ctypes.sizeof(Mi355SatStats) == 8 * (9 + 4 + 8 + 8 + 1)       # as the compiler laid them out (30 x 8 bytes)
+    assert st_size.value == ctypes.sizeof(Mi355SatStats) == 8 * (9 + 4 + 8 + 8 + 2)       # as the compiler laid them out (31 x 8 bytes)
     L.mi355sat_signature.restype = ctypes.c_char_p
     assert b"mi355sat" in L.mi355sat_signature()
     L.mi355sat_release_cached_memory()        # nothing parked, no device touched: must be a no-op

@@ -442,6 +442,76 @@ def test_emulated_subsumption_kernel_removes_and_strengthens():
     s.close()
 
 
+def test_emulated_variable_elimination_rebuilds_models_and_keeps_assumptions():
+    """Bounded variable elimination (`SimpSolver::eliminate` of the reference's backend, opts.simp = 2) on small
+    hand-made formulas: x3 and x6 occur only in a few clauses and are resolved away; the model that comes back
+    gives them values satisfying the ORIGINAL clauses; a variable named in an assumption is not eliminated, so every
+    assumption set gets the oracle's verdict."""
+    import itertools
+    cl = [[1, 3], [-3, 2, 4], [-3, 5], [3, -4, -5], [6, 1, 2], [-6, -1], [-6, -2, 5], [4, 5, 7, 8], [-7, -8, 1], [7, -5, 2]]
+    s = emu_solver(workers=1, simp=2)
+    for c in cl:
+        s.add_clause(c)
+    assert s.solve() == SolverResult.Sat
+    assert s.stats()["simp_eliminated"] >= 2
+    assert ora.check_model(*ora.to_csr(cl), s.full_solution(8)) == -1
+    s.close()
+    sets = [[v if b else -v for v, b in zip((3, 6, 1), bits)] for bits in itertools.product([0, 1], repeat=3)]
+    s = emu_solver(workers=2, simp=2)
+    for c in cl:
+        s.add_clause(c)
+    res = s.solve_batch(sets)
+    for i, (a, r) in enumerate(zip(sets, res)):
+        o = ora.OracleSolver()
+        o.add_cnf(*ora.to_csr(cl))
+        assert r.value == o.solve(a), a
+        if r == SolverResult.Sat:
+            assert ora.check_model(*ora.to_csr(cl + [[l] for l in a]), s.solution_of(i, 8)) == -1
+    s.close()
+
+
+@pytest.mark.parametrize("terrain,pset,k,want", [("ex1", "1x1", 3, "Sat"), ("ex1", "default", 1, "Sat"), ("ex3", "1x1", 3, "Unsat")])
+def test_emulated_variable_elimination_on_the_encoder_s_formulas(tmp_path, terrain, pset, k, want):
+    """The same on the encoder's CNFs: verdicts as without it, layouts valid against the original clauses and the
+    terrain, and the DRUP proof - the resolvents are lemmas of it - accepted by the oracle's RUP checker."""
+    from timberborn_support_solver_amd.dimacs import read_drup
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+    proof = str(tmp_path / "p.drup")
+    s = emu_solver(workers=2, simp=2)
+    if want == "Unsat":
+        s.set_proof_path(proof)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    r = s.solve()
+    assert r.name == want
+    assert s.stats()["simp_eliminated"] > 0
+    if r == SolverResult.Sat:
+        check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
+    else:
+        assert ora.check_rup(cnf.lits, cnf.offsets, cnf.n_vars, read_drup(proof)) == 1
+    s.close()
+
+
+def test_emulated_variable_elimination_keeps_a_sweep_s_bounds():
+    """The bounds of a sweep are assumptions on the totalizer's outputs: those variables survive the elimination and
+    every bound has its golden verdict, with models valid in the caller's variables."""
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 8}), sweep=True)
+    ks = [8, 6, 5, 4, 3, 2]                                                    # k* = 4
+    sets = [[-int(cnf.card_outputs[k])] if k < 8 else [] for k in ks]
+    s = emu_solver(workers=6, simp=2)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    res = s.solve_batch(sets)
+    assert s.stats()["simp_eliminated"] > 0
+    for i, (k, r) in enumerate(zip(ks, res)):
+        assert r.name == ("Sat" if k >= 4 else "Unsat"), k
+        if r == SolverResult.Sat:
+            check_sat_answer(cnf, s.solution_of(i, cnf.n_vars), enc, grid, k)
+    s.close()
+
+
 def test_emulated_sweep_priorities_and_reopening_keep_the_answers():
     """mi355sat_sweep_set_weights / mi355sat_sweep_reopen are scheduling only: whatever the caller's priorities and
     however often bounds are withdrawn and taken up again, every decided bound has its golden verdict."""

@@ -379,6 +379,7 @@ def test_sweep_with_exchange_migration_and_withdrawn_instances_finds_the_cut():
 @pytest.mark.parametrize("terrain,pset,k0,kstar,kw", [("rect16x16", "default", 40, 4, dict(workers=1024, slice_ms=2)),
                                                       ("ex3", "default", 20, 1, dict(workers=1024, slice_ms=2)),
                                                       ("ex2", "default", 12, 4, dict(workers=1024, slice_ms=2)),
+                                                      ("ex2", "default", 12, 4, dict(simp=2)),      # (variable elimination: the bounds' outputs are kept)
                                                       ("rect24x24", "default", 24, 9, dict())])
 def test_solver_loop_sweep_reaches_the_same_optimum_as_the_sequential_loop(terrain, pset, k0, kstar, kw):
     """The last case runs with the default options long enough to leave the ramp-up: the fleet grows from one
@@ -464,18 +465,20 @@ def test_rectangular_type_limit_on_the_gpu():
                                                   ("rect24x24", "default", 8, "Unsat"), ("rect24x24", "default", 9, "Sat")])
 def test_simplification_before_search_keeps_verdicts_and_models(terrain, pset, k, want):
     """SURVEY 8 f3 (`simp::Glucose`, crates/repl/src/main.rs:17): with the device-side simplification on (the
-    default: equivalent literals, failed-literal probing, subsumption) and off, the verdict is the golden one;
-    models are in the caller's variables and satisfy the ORIGINAL clauses; the counters show it ran."""
+    default: equivalent literals, failed-literal probing, subsumption), with bounded variable elimination on top
+    (simp = 2: `SimpSolver::eliminate`) and off, the verdict is the golden one; models are in the caller's variables
+    and satisfy the ORIGINAL clauses - eliminated variables included; the counters show what ran."""
     grid = make_grid(terrain)
     enc = Encoding.encode(platform_defs(pset), grid)
     cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
-    for simp in (0, -1):
+    for simp in (0, 2, -1):
         s = Mi355Sat(simp=simp)
         s.add_cnf(cnf.lits, cnf.offsets)
         r = solve_within(s, HARD_RUNG_LIMIT_S)
         assert r.name == want, (terrain, pset, k, simp)
         st = s.stats()
-        assert (st["simp_units"] + st["simp_equivalences"] + st["simp_clauses_removed"] > 0) == (simp == 0)
+        assert (st["simp_units"] + st["simp_equivalences"] + st["simp_clauses_removed"] > 0) == (simp >= 0)
+        assert (st["simp_eliminated"] > 0) == (simp == 2)
         if r == SolverResult.Sat:
             check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
         s.close()

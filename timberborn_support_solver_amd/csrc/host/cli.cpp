@@ -1,5 +1,5 @@
 // tbs_cli — minimal command-line driver of the solve path (NOT the reference's REPL/UI):
-//   tbs_cli rect W H [-l1:K] [--platforms default|1x1] [--workers N] [--sweep] [--gpu N] [--seed N] [--verbose] [--no-simp]
+//   tbs_cli rect W H [-l1:K] [--platforms default|1x1] [--workers N] [--sweep] [--gpu N] [--seed N] [--verbose] [--no-simp] [--eliminate]
 //   tbs_cli file PATH.toml [-l1:K] ...
 // Mirrors `solve -l<dims>:<n>` of crates/repl/src/main.rs:44-75,248-261: encode once, then solver_loop.
 // Ctrl-C calls mi355sat_interrupt (main.rs:297-324).
@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
     try {
         if (argc < 3) {
             fprintf(stderr, "usage: %s rect W H | file PATH [-l<dims>:<n>]... [--platforms default|1x1] [--workers N] [--sweep] [--gpu N] [--seed N] "
-                            "[--verbose] [--no-simp]\n", argv[0]);
+                            "[--verbose] [--no-simp] [--eliminate]\n", argv[0]);
             return 2;
         }
         WorldGrid grid;
@@ -55,6 +55,7 @@ int main(int argc, char** argv) {
             else if (arg == "--seed" && a + 1 < argc) opts.seed = strtoull(argv[++a], nullptr, 10);   // diversification seed
             else if (arg == "--verbose") opts.verbose = 1;
             else if (arg == "--no-simp") opts.simp = -1;
+            else if (arg == "--eliminate") opts.simp = 2;     // + bounded variable elimination before every search
             else if (arg == "--sweep") sweep = true;   // the bounds below the first one as one batch on the device
             else throw std::runtime_error("unknown argument " + arg);
         }

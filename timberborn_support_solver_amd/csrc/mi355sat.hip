@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -311,6 +312,9 @@ struct SlabBuf {
 
 }  // namespace
 
+// One eliminated variable: literal x of it and the clauses (elim_lits[begin, end), -1 terminated, x included) that held x.
+struct MsElim { int32_t x; uint32_t begin, end; };
+
 struct mi355sat {
     mi355sat_opts opts{};
     int device = 0;
@@ -361,6 +365,8 @@ struct mi355sat {
     std::vector<uint32_t> perm;                // caller's variable index -> device variable index (Prepared::perm)
     std::vector<int32_t> subst;                // per caller variable: the literal (2*var + neg) that replaced it, or itself
     std::vector<int32_t> simp_proof;           // DRUP lemmas of the simplification (internal literals, -1 terminated)
+    std::vector<MsElim> elims;                 // variables eliminated before search and the clauses that rebuild their values
+    std::vector<int32_t> elim_lits;
     struct SweepHolder* sweep = nullptr;        // stepwise sweep in progress (mi355sat_sweep_*)
 };
 
@@ -462,7 +468,10 @@ struct Formula {
     std::vector<int32_t> subst;              // per variable: the literal that replaces it (2*v = itself)
     std::vector<int32_t> proof;              // DRUP lemmas justifying units / equivalences / rewritten clauses (-1 terminated)
     bool log_proof = false;
-    uint64_t n_failed = 0, n_necessary = 0, n_equiv = 0, n_subsumed = 0, n_strengthened = 0;
+    std::vector<int32_t> frozen_lits;        // internal literals (caller's numbering) whose variables must survive: the assumptions
+    std::vector<MsElim> elims;               // eliminated variables in elimination order + the clauses that rebuild their value
+    std::vector<int32_t> elim_lits;
+    uint64_t n_failed = 0, n_necessary = 0, n_equiv = 0, n_subsumed = 0, n_strengthened = 0, n_eliminated = 0;
     size_t n_clauses() const { return no.size() - 1; }
     int8_t lv(int32_t l) const { int8_t v = val[l >> 1]; return (l & 1) ? (int8_t)-v : v; }
     bool assign_unit(int32_t l) {            // false on contradiction
@@ -704,12 +713,22 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     uint32_t* val = (uint32_t*)(T + L.val);      // zero = every variable unassigned
     MsVarRec* vrec = (MsVarRec*)(T + L.vrec);
     int32_t* vm_order = (int32_t*)(T + L.vm_order);
-    for (uint32_t e = 0; e < nv; e++) {   // initial decision order: the caller's numbering, highest first
-        const uint32_t v = P.perm[e];
-        vrec[v] = MsVarRec{0, MS_REASON_NONE, 0, 0, /*phase=*/1, /*seen=*/0};
-        ((int32_t*)(T + L.vm_pos))[v] = (int32_t)(nv - 1 - e);
-        vm_order[nv - 1 - e] = (int32_t)v;
-    }
+    // initial decision order: the caller's numbering (the search starts at position nv - 1); variables that occur in no
+    // clause (replaced by an equivalent literal, eliminated) behind all others
+    std::vector<uint8_t> occurs(nv, 0);
+    for (const MsClauseHdr& h : P.cl_hdr)      // (cl_lits carries padding behind the last clause)
+        for (uint32_t k = 0; k < h.size; k++) occurs[P.cl_lits[h.start + k] >> 1] = 1;
+    for (size_t t = 0; t < P.lit_hdr.size(); t++) if (P.lit_hdr[t].bin_n || P.lit_hdr[t].tern_n) occurs[t >> 1] = 1;
+    uint32_t pos = nv;
+    for (int pass = 0; pass < 2; pass++)
+        for (uint32_t e = 0; e < nv; e++) {
+            const uint32_t v = P.perm[e];
+            if ((occurs[v] != 0) != (pass == 0)) continue;
+            pos--;
+            vrec[v] = MsVarRec{0, MS_REASON_NONE, 0, 0, /*phase=*/1, /*seen=*/0};
+            ((int32_t*)(T + L.vm_pos))[v] = (int32_t)pos;
+            vm_order[pos] = (int32_t)v;
+        }
     int32_t* trail = (int32_t*)(T + L.trail);
     for (size_t i = 0; i < P.units.size(); i++) {
         int32_t l = P.units[i];
@@ -1088,8 +1107,167 @@ uint64_t device_subsume(mi355sat& s, Formula& F) {
     return n;
 }
 
+inline bool bve_enabled(const mi355sat& s) { return s.opts.simp == 2; }
+
+// Bounded variable elimination - `SimpSolver::eliminate` of the reference's backend ([ext] Een & Biere 2005, MiniSat's
+// limits: no more clauses than before (grow = 0), no resolvent longer than 20 literals).  A variable x that is not
+// frozen (assumptions are) is resolved away: every clause with x against every clause with ~x, tautologies dropped;
+// if that does not make the formula larger, the resolvents replace the clauses of x.  The clauses of the smaller side
+// are kept aside (F.elims): in reverse elimination order they give x its value in a model of the rest
+// (`extendModel`).  Host code: occurrence lists and a cost-ordered queue, a few 10 ms on these formulas; every
+// resolvent is a RUP lemma of the proof.
+uint64_t bve_eliminate(Formula& F) {
+    if (F.unsat || F.n_clauses() == 0) return 0;
+    const uint32_t nv = F.nv;
+    const int CLAUSE_LIM = 20, OCC_LIM = 400;
+    std::vector<uint8_t> frozen(nv, 0), gone(nv, 0);
+    for (int32_t l : F.frozen_lits) {
+        while (F.subst[l >> 1] != 2 * (l >> 1)) l = F.subst[l >> 1] ^ (l & 1);
+        frozen[l >> 1] = 1;
+    }
+    std::vector<int32_t>& nl = F.nl;
+    std::vector<uint64_t>& no = F.no;
+    std::vector<uint8_t> alive(F.n_clauses(), 1);
+    std::vector<std::vector<uint32_t>> occ(2 * (size_t)nv);
+    std::vector<uint32_t> n_occ(2 * (size_t)nv, 0);
+    for (size_t c = 0; c < F.n_clauses(); c++)
+        for (uint64_t k = no[c]; k < no[c + 1]; k++) { occ[nl[k]].push_back((uint32_t)c); n_occ[nl[k]]++; }
+    auto cost = [&](uint32_t v) { return (uint64_t)n_occ[2 * v] * n_occ[2 * v + 1]; };
+    typedef std::pair<uint64_t, uint32_t> QE;
+    std::priority_queue<QE, std::vector<QE>, std::greater<QE>> heap;
+    for (uint32_t v = 0; v < nv; v++)
+        if (!frozen[v] && !F.val[v] && (n_occ[2 * v] || n_occ[2 * v + 1])) heap.push({cost(v), v});
+    std::vector<uint32_t> stamp(2 * (size_t)nv, 0);
+    uint32_t epoch = 0;
+    std::vector<uint32_t> P, N;
+    std::vector<int32_t> res;
+    uint64_t n_elim = 0;
+    auto kill = [&](uint32_t c) {
+        alive[c] = 0;
+        for (uint64_t k = no[c]; k < no[c + 1]; k++) {
+            const int32_t l = nl[k];
+            n_occ[l]--;
+            const uint32_t u = (uint32_t)(l >> 1);
+            if (!frozen[u] && !gone[u] && !F.val[u]) heap.push({cost(u), u});
+        }
+    };
+    while (!heap.empty() && !F.unsat) {
+        const QE top = heap.top();
+        heap.pop();
+        const uint32_t v = top.second;
+        if (gone[v] || F.val[v] || top.first != cost(v)) continue;     // stale entry (a fresher one is in the queue)
+        const int32_t x = 2 * (int32_t)v, nx = x + 1;
+        if (n_occ[x] + n_occ[nx] == 0) continue;
+        if (n_occ[x] > (uint32_t)OCC_LIM || n_occ[nx] > (uint32_t)OCC_LIM || top.first > 4096) continue;
+        P.clear();
+        N.clear();
+        for (uint32_t c : occ[x]) if (alive[c]) P.push_back(c);
+        for (uint32_t c : occ[nx]) if (alive[c]) N.push_back(c);
+        occ[x] = P;
+        occ[nx] = N;
+        // count the non-tautological resolvents
+        size_t cnt = 0;
+        bool ok = true;
+        for (size_t i = 0; i < P.size() && ok; i++) {
+            epoch++;
+            const uint32_t c = P[i];
+            const int clen = (int)(no[c + 1] - no[c]);
+            for (uint64_t k = no[c]; k < no[c + 1]; k++) stamp[nl[k]] = epoch;
+            for (size_t j = 0; j < N.size() && ok; j++) {
+                const uint32_t d = N[j];
+                int extra = 0;
+                bool taut = false;
+                for (uint64_t k = no[d]; k < no[d + 1] && !taut; k++) {
+                    const int32_t l = nl[k];
+                    if (l == nx) continue;
+                    if (stamp[l ^ 1] == epoch) taut = true;
+                    else if (stamp[l] != epoch) extra++;
+                }
+                if (taut) continue;
+                if (++cnt > P.size() + N.size() || clen - 1 + extra > CLAUSE_LIM) ok = false;
+            }
+        }
+        if (!ok) continue;
+        // eliminate: keep the smaller side for the model, add the resolvents, drop both sides
+        {
+            const bool pos_side = P.size() <= N.size();
+            const std::vector<uint32_t>& side = pos_side ? P : N;
+            MsElim e{pos_side ? x : nx, (uint32_t)F.elim_lits.size(), 0};
+            for (uint32_t c : side) {
+                F.elim_lits.insert(F.elim_lits.end(), nl.begin() + no[c], nl.begin() + no[c + 1]);
+                F.elim_lits.push_back(-1);
+            }
+            e.end = (uint32_t)F.elim_lits.size();
+            F.elims.push_back(e);
+        }
+        gone[v] = 1;
+        for (size_t i = 0; i < P.size() && !F.unsat; i++)
+            for (size_t j = 0; j < N.size() && !F.unsat; j++) {
+                const uint32_t c = P[i], d = N[j];
+                res.clear();
+                for (uint64_t k = no[c]; k < no[c + 1]; k++) if (nl[k] != x) res.push_back(nl[k]);
+                for (uint64_t k = no[d]; k < no[d + 1]; k++) if (nl[k] != nx) res.push_back(nl[k]);
+                std::sort(res.begin(), res.end());
+                res.erase(std::unique(res.begin(), res.end()), res.end());
+                bool taut = false;
+                for (size_t q = 0; q + 1 < res.size(); q++) taut = taut || (res[q] ^ 1) == res[q + 1];
+                if (taut) continue;
+                F.lemma(res);
+                if (res.size() <= 1) {
+                    if (res.empty() || !F.assign_unit(res[0])) F.unsat = true;
+                    continue;
+                }
+                const uint32_t id = (uint32_t)F.n_clauses();
+                nl.insert(nl.end(), res.begin(), res.end());
+                no.push_back(nl.size());
+                alive.push_back(1);
+                for (int32_t l : res) { occ[l].push_back(id); n_occ[l]++; }
+            }
+        for (uint32_t c : P) kill(c);
+        for (uint32_t c : N) kill(c);
+        n_elim++;
+    }
+    if (!n_elim) return 0;
+    F.n_eliminated += n_elim;
+    std::vector<int32_t> nl2;
+    std::vector<uint64_t> no2{0};
+    nl2.reserve(nl.size());
+    for (size_t c = 0; c < F.n_clauses(); c++) {
+        if (!alive[c]) continue;
+        nl2.insert(nl2.end(), nl.begin() + no[c], nl.begin() + no[c + 1]);
+        no2.push_back(nl2.size());
+    }
+    F.nl.swap(nl2);
+    F.no.swap(no2);
+    return n_elim;
+}
+
+// The values of the eliminated variables in a model of the remaining formula (MiniSat's extendModel): last eliminated
+// first; x is false unless one of its kept clauses has every other literal false.  model: 1 true / -1 false per variable.
+void extend_model(const std::vector<MsElim>& elims, const std::vector<int32_t>& elim_lits, std::vector<int8_t>& model) {
+    for (size_t i = elims.size(); i-- > 0;) {
+        const MsElim& e = elims[i];
+        const size_t v = (size_t)(e.x >> 1);
+        if (v >= model.size()) continue;
+        bool need = false;
+        for (uint32_t k = e.begin; k < e.end && !need;) {
+            bool others_false = true;
+            for (; elim_lits[k] >= 0; k++) {
+                const int32_t l = elim_lits[k];
+                if (l == e.x || (size_t)(l >> 1) >= model.size()) continue;
+                const int8_t m = model[l >> 1];
+                if (((l & 1) ? -m : m) > 0) others_false = false;
+            }
+            k++;
+            need = others_false;
+        }
+        model[v] = (int8_t)(((e.x & 1) != 0) == need ? -1 : 1);
+    }
+}
+
 // The whole pipeline: units, then rounds of {equivalent literals, probing} while they find something, then
-// subsumption.  Everything it derives is a consequence of the caller's formula alone (never of assumptions).
+// subsumption, then variable elimination (and subsumption among its resolvents).  Everything it derives is a
+// consequence of the caller's formula alone (never of assumptions); the assumptions' variables are not eliminated.
 void simplify_formula(mi355sat& s, Formula& F) {
     propagate_units(F);
     if (s.opts.simp < 0 || F.unsat) return;
@@ -1107,6 +1285,17 @@ void simplify_formula(mi355sat& s, Formula& F) {
         propagate_units(F);
         if (!n) break;
     }
+    const double t1 = now_s();
+    if (bve_enabled(s) && !F.unsat && bve_eliminate(F)) {
+        propagate_units(F);
+        for (int pass = 0; pass < 2 && !F.unsat; pass++) {
+            const uint64_t n = device_subsume(s, F);
+            propagate_units(F);
+            if (!n) break;
+        }
+    }
+    if (s.opts.verbose && bve_enabled(s))
+        fprintf(stderr, "[mi355sat] variable elimination %.3f s: %llu variables\n", now_s() - t1, (unsigned long long)F.n_eliminated);
     if (s.opts.verbose)
         fprintf(stderr, "[mi355sat] simplification %.3f s: clauses %zu -> %zu, literals %zu -> %zu, units +%zu (failed literals %llu, necessary %llu), "
                 "equivalent variables %llu, subsumed %llu, strengthened %llu%s\n", now_s() - t0, c0, F.n_clauses(), l0, F.nl.size(),
@@ -1151,12 +1340,17 @@ void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_
     if (s.n_vars)
         HIPCHK(hipMemcpy(words.data(), s.d_slabs.p + (size_t)worker * s.L.slab_bytes + s.L.val,
                          4 * (((size_t)s.n_vars + 15) / 16), hipMemcpyDeviceToHost));
-    out.assign(n_vars_out, 0);
-    for (uint64_t v = 0; v < n_vars_out && v < s.n_vars; v++) {
+    // the device's values, then the eliminated variables (their kept clauses mention device variables and variables
+    // eliminated later only), then the variables replaced by an equivalent literal (representatives have smaller indices)
+    std::vector<int8_t> m(s.n_vars, 0);
+    for (uint64_t v = 0; v < s.n_vars; v++) m[v] = asg_of(words.data(), s.perm[v]) == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
+    extend_model(s.elims, s.elim_lits, m);
+    for (uint64_t v = 0; v < s.n_vars; v++) {
         const int32_t r = v < s.subst.size() ? s.subst[v] : 2 * (int32_t)v;
-        if (r != 2 * (int32_t)v && (uint64_t)(r >> 1) < v) out[v] = (r & 1) ? (int8_t)-out[r >> 1] : out[r >> 1];   // representatives have smaller indices
-        else out[v] = asg_of(words.data(), s.perm[v]) == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
+        if (r != 2 * (int32_t)v && (uint64_t)(r >> 1) < v) m[v] = (r & 1) ? (int8_t)-m[r >> 1] : m[r >> 1];
     }
+    out.assign(n_vars_out, 0);
+    for (uint64_t v = 0; v < n_vars_out && v < s.n_vars; v++) out[v] = m[v];
 }
 
 struct SliceResult { float ms; };
@@ -1338,9 +1532,14 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
         Formula F;
         normalise(s, F);
         F.log_proof = !s.proof_path.empty();
+        for (int32_t d : assump)
+            if (d != 0 && (uint64_t)(d < 0 ? -(int64_t)d : d) <= F.nv) F.frozen_lits.push_back(to_internal(d));
         simplify_formula(s, F);
         build_csr(s, F, /*units_propagated=*/true, P);
         s.subst = F.subst;
+        s.elims.swap(F.elims);
+        s.elim_lits.swap(F.elim_lits);
+        s.stats.simp_eliminated = F.n_eliminated;
         s.simp_proof.swap(F.proof);
         s.stats.simp_units = F.n_failed + F.n_necessary;
         s.stats.simp_equivalences = F.n_equiv;
@@ -1975,7 +2174,7 @@ int mi355sat_sweep_step(mi355sat* s, int32_t* results_out, uint64_t* n_decided) 
         s->stats.kernel_launches = keep.kernel_launches;
         s->stats.workers = keep.workers;
         s->stats.simp_units = keep.simp_units; s->stats.simp_equivalences = keep.simp_equivalences;
-        s->stats.simp_clauses_removed = keep.simp_clauses_removed;
+        s->stats.simp_clauses_removed = keep.simp_clauses_removed; s->stats.simp_eliminated = keep.simp_eliminated;
         s->stats.solve_seconds = keep.solve_seconds + (now_s() - t0);
         accumulate_stats(*s, sw.sts);
         return rc;

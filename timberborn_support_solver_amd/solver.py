@@ -53,7 +53,7 @@ class Mi355SatStats(ctypes.Structure):
                  "bcp_steps", "bcp_requeued")] + \
                [("shared_exported", ctypes.c_uint64), ("shared_imported", ctypes.c_uint64), ("shared_imported_units", ctypes.c_uint64),
                 ("simp_units", ctypes.c_uint64), ("simp_equivalences", ctypes.c_uint64), ("simp_clauses_removed", ctypes.c_uint64),
-                ("workers", ctypes.c_uint64)]
+                ("workers", ctypes.c_uint64), ("simp_eliminated", ctypes.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
