@@ -858,12 +858,18 @@ void grow_workers(mi355sat& s, uint32_t n_instances, uint32_t target) {
     if (s.n_alloc >= target) return;
     const uint32_t old = s.n_alloc;
     const double t0 = now_s();
-    SlabBuf big;
-    big.alloc((size_t)target * s.L.slab_bytes, s.device);
-    HIPCHK(hipMemcpyAsync(big.p, s.d_slabs.p, (size_t)old * s.L.slab_bytes, hipMemcpyDeviceToDevice, s.stream));
-    HIPCHK(hipStreamSynchronize(s.stream));
-    std::swap(big.p, s.d_slabs.p); std::swap(big.n, s.d_slabs.n); std::swap(big.cap, s.d_slabs.cap); std::swap(big.dev, s.d_slabs.dev);
-    big.release();   // the small buffer (parked if nothing larger is)
+    if (s.d_slabs.cap >= (size_t)target * s.L.slab_bytes) {
+        // the buffer came from the parked one of an earlier handle (or of this handle's probing) and has the room
+        // already: no allocation (hipMalloc of 8.7 GiB is 0.25 s - a quarter of the rect 24x24 ladder), no move
+        s.d_slabs.n = (size_t)target * s.L.slab_bytes;
+    } else {
+        SlabBuf big;
+        big.alloc((size_t)target * s.L.slab_bytes, s.device);
+        HIPCHK(hipMemcpyAsync(big.p, s.d_slabs.p, (size_t)old * s.L.slab_bytes, hipMemcpyDeviceToDevice, s.stream));
+        HIPCHK(hipStreamSynchronize(s.stream));
+        std::swap(big.p, s.d_slabs.p); std::swap(big.n, s.d_slabs.n); std::swap(big.cap, s.d_slabs.cap); std::swap(big.dev, s.d_slabs.dev);
+        big.release();   // the small buffer (parked if nothing larger is)
+    }
     s.n_alloc = target;
     replicate_template(s, old, s.n_alloc);
     hipLaunchKernelGGL(ms_customize_kernel, dim3(s.n_alloc - old), dim3(256), 0, s.stream, s.L, s.d_slabs.p, s.n_alloc,
@@ -1013,10 +1019,15 @@ uint64_t device_probe(mi355sat& s, Formula& F) {
     std::vector<uint32_t> inv(P.perm.size());
     for (uint32_t e = 0; e < P.perm.size(); e++) inv[P.perm[e]] = e;
     auto to_caller = [&](int32_t dl) { return 2 * (int32_t)inv[dl >> 1] | (dl & 1); };
-    const size_t fact_row = 3 * (((size_t)P.n_vars + 1) / 3);
-    std::vector<int32_t> res((size_t)W * cap), facts((size_t)W * std::max<size_t>(fact_row, 1)), nfacts(W);
+    const size_t fact_cap = 3 * (((size_t)P.n_vars + 1) / 3);
+    std::vector<int32_t> res((size_t)W * cap), nfacts(W);
     HIPCHK(hipMemcpy2D(res.data(), 4 * (size_t)cap, s.d_slabs.p + s.L.script, s.L.slab_bytes, 4 * (size_t)cap, W, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy2D(nfacts.data(), 4, s.d_slabs.p + s.L.learnt_buf, s.L.slab_bytes, 4, W, hipMemcpyDeviceToHost));
+    // only as many columns of the fact rows as the busiest worker filled (a full row is n_vars ints per worker)
+    size_t fact_used = 0;
+    for (uint32_t w = 0; w < W; w++) fact_used = std::max(fact_used, 3 * (size_t)std::max(nfacts[w], 0));
+    const size_t fact_row = std::min(fact_cap, fact_used);
+    std::vector<int32_t> facts((size_t)W * std::max<size_t>(fact_row, 1));
     if (fact_row) HIPCHK(hipMemcpy2D(facts.data(), 4 * fact_row, s.d_slabs.p + s.L.toclear, s.L.slab_bytes, 4 * fact_row, W, hipMemcpyDeviceToHost));
     std::vector<MsState> sts;
     gather_states(s, sts);
@@ -1030,7 +1041,7 @@ uint64_t device_probe(mi355sat& s, Formula& F) {
                 if (F.val[a >> 1] == 0) { F.lemma({a ^ 1}); F.n_failed++; n_new++; }
                 if (!F.assign_unit(a ^ 1)) F.unsat = true;
             }
-        for (int32_t f = 0; f < nfacts[w] && !F.unsat; f++) {
+        for (int32_t f = 0; f < nfacts[w] && 3 * ((size_t)f + 1) <= fact_row && !F.unsat; f++) {
             const int32_t* t = facts.data() + (size_t)w * fact_row + 3 * (size_t)f;
             const int32_t m = to_caller(t[1]), a = to_caller(t[2]);
             if (t[0] == 1) {                                               // a -> m and ~a -> m
@@ -1273,18 +1284,27 @@ void simplify_formula(mi355sat& s, Formula& F) {
     if (s.opts.simp < 0 || F.unsat) return;
     const double t0 = now_s();
     const size_t c0 = F.n_clauses(), l0 = F.nl.size(), u0 = F.units.size();
+    double t_els = 0, t_probe = 0, t_sub = 0;
     for (int round = 0; round < 3 && !F.unsat; round++) {
+        double ta = now_s();
         uint64_t n = els_scc(F);
         propagate_units(F);
+        t_els += now_s() - ta;
+        ta = now_s();
         n += device_probe(s, F);
         propagate_units(F);
+        t_probe += now_s() - ta;
         if (!n) break;
     }
     for (int pass = 0; pass < 3 && !F.unsat; pass++) {
+        const double ta = now_s();
         const uint64_t n = device_subsume(s, F);
         propagate_units(F);
+        t_sub += now_s() - ta;
         if (!n) break;
     }
+    if (s.opts.verbose)
+        fprintf(stderr, "[mi355sat] simplification stages: equivalent literals %.3f s, probing %.3f s, subsumption %.3f s\n", t_els, t_probe, t_sub);
     const double t1 = now_s();
     if (bve_enabled(s) && !F.unsat && bve_eliminate(F)) {
         propagate_units(F);
