@@ -1640,7 +1640,10 @@ DEV bool vivify_pass(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls
 }
 
 // BCP reached a fixpoint without conflict: restart? reduce? then assumptions / next decision.
-template <bool LV>
+// VIV = with vivification.  It is left out of the full-fleet build: its code (a second copy of the BCP loop) in the
+// cold call costs that build's hot loop registers (81 -> 131 spilled VGPRs, -7 % propagations/s on the 64x64 sweep), and
+// a worker of 4096 makes too few conflicts for it to matter there.
+template <bool LV, bool VIV = true>
 DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls, uint32_t reduce_first,
                           uint32_t reduce_inc) {
     PROF_DECL
@@ -1660,7 +1663,7 @@ DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
             wave_fence();
         }
     }
-    if (ls.vivify && w.n_levels == 0 && ls.conflicts >= ls.next_vivify) {
+    if (VIV && ls.vivify && w.n_levels == 0 && ls.conflicts >= ls.next_vivify) {
         ls.next_vivify = ls.conflicts + 400;
         if (vivify_pass<LV>(w, sh, L, ls)) rebuild_watches(w, sh, L);   // shrunk clauses watch their new first two literals
         if (w.status != MS_ST_RUNNING || w.qhead < w.trail_n) return;   // a new unit: BCP first
@@ -1700,16 +1703,16 @@ DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     enqueue_uniform<LV>(w, sh, L, next, MS_REASON_NONE);
     PROF_MARK(PF_DECIDE);
 }
-template <bool LV, bool COPY>
+template <bool LV, bool COPY, bool VIV>
 DEV_COLD void on_fixpoint(Wk& wr, const MsShared& shr, const MsLayout& Lr, LoopState& lsr, uint32_t reduce_first, uint32_t reduce_inc,
                           MsKernarg ka) {
-    if (!COPY) { on_fixpoint_body<LV>(wr, shr, Lr, lsr, reduce_first, reduce_inc); return; }
+    if (!COPY) { on_fixpoint_body<LV, VIV>(wr, shr, Lr, lsr, reduce_first, reduce_inc); return; }
     MS_ARGS_FROM_KERNARG(sh, L, ka, shr, Lr)
     Wk w = wr;
     wk_uniformize(w);
     LoopState ls = lsr;
     ls_uniformize(ls);
-    on_fixpoint_body<LV>(w, sh, L, ls, reduce_first, reduce_inc);
+    on_fixpoint_body<LV, VIV>(w, sh, L, ls, reduce_first, reduce_inc);
     wr = w;
     lsr = ls;
 }
@@ -1822,7 +1825,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
                 if (ONE) on_fixpoint_body<LV>(w, sh, L, ls, prm.reduce_first, prm.reduce_inc);
                 else {
                     Wk t = w;
-                    on_fixpoint<LV, WPS == 2>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc, ka);
+                    on_fixpoint<LV, WPS == 2, WPS == 2>(t, sc, lc, ls, prm.reduce_first, prm.reduce_inc, ka);
                     w = t;
                     wk_uniformize(w);
                 }
