@@ -496,17 +496,17 @@ def test_emulated_variable_elimination_on_the_encoder_s_formulas(tmp_path, terra
 def test_emulated_variable_elimination_keeps_a_sweep_s_bounds():
     """The bounds of a sweep are assumptions on the totalizer's outputs: those variables survive the elimination and
     every bound has its golden verdict, with models valid in the caller's variables."""
-    grid = make_grid("rect8x8")
+    grid = make_grid("ex1")
     enc = Encoding.encode(platform_defs("1x1"), grid)
-    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 8}), sweep=True)
-    ks = [8, 6, 5, 4, 3, 2]                                                    # k* = 4
-    sets = [[-int(cnf.card_outputs[k])] if k < 8 else [] for k in ks]
-    s = emu_solver(workers=6, simp=2)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 6}), sweep=True)
+    ks = [6, 4, 3, 2, 1]                                                       # k* = 3
+    sets = [[-int(cnf.card_outputs[k])] if k < 6 else [] for k in ks]
+    s = emu_solver(workers=5, simp=2)
     s.add_cnf(cnf.lits, cnf.offsets)
     res = s.solve_batch(sets)
     assert s.stats()["simp_eliminated"] > 0
     for i, (k, r) in enumerate(zip(ks, res)):
-        assert r.name == ("Sat" if k >= 4 else "Unsat"), k
+        assert r.name == ("Sat" if k >= 3 else "Unsat"), k
         if r == SolverResult.Sat:
             check_sat_answer(cnf, s.solution_of(i, cnf.n_vars), enc, grid, k)
     s.close()
