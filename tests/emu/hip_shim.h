@@ -114,12 +114,23 @@ static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T>
 static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+// (the kernels call these on plain and on volatile-qualified pointers)
 template <class T>
-static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
-template <class T>
-static inline T __hip_atomic_fetch_or(T* p, T v, int, int) { T o = *p; *p = o | v; return o; }
-template <class T>
-static inline T __hip_atomic_fetch_and(T* p, T v, int, int) { T o = *p; *p = o & v; return o; }
+static inline T __hip_atomic_load(const volatile T* p, int, int) { return *p; }
+template <class T, class V>
+static inline T __hip_atomic_fetch_or(volatile T* p, V v, int, int) { T o = *p; *p = o | (T)v; return o; }
+template <class T, class V>
+static inline T __hip_atomic_fetch_and(volatile T* p, V v, int, int) { T o = *p; *p = o & (T)v; return o; }
+template <class T, class V>
+static inline T __hip_atomic_fetch_add(volatile T* p, V v, int, int) { T o = *p; *p = o + (T)v; return o; }
+template <class T, class V>
+static inline bool __hip_atomic_compare_exchange_strong(volatile T* p, T* expected, V v, int, int, int) {
+    T o = *p;
+    if (o == *expected) { *p = (T)v; return true; }
+    *expected = o;
+    return false;
+}
 // dynamic LDS: one static 160 KiB block per (sequentially executed) workgroup
 #define HIP_DYNAMIC_SHARED(type, var) static type var[163840 / sizeof(type)];
 

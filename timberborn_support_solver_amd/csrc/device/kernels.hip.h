@@ -63,18 +63,47 @@ enum { PF_OFF = 0, PF_BIN, PF_TERN, PF_LONG, PF_CLOSE, PF_ANALYZE, PF_BACKJUMP, 
 // cold paths are real calls: keeps them out of the hot loop's register allocation
 #define DEV_COLD __device__ __noinline__
 
+// ---- address spaces ----------------------------------------------------------------
+// A HIP pointer is generic ("flat") unless its type says otherwise, and the compiler's address-space inference never
+// rewrites a VOLATILE access: round 2's kernels made every LDS access (ring, claim set, assignment, marks: all through
+// `volatile T*` fields of Wk) and most slab accesses (pointers rebuilt from integers, or handed through scratch copies
+// of Wk) FLAT instructions - 472 flat_load / 377 flat_store and ONE ds_read in the one-worker-per-SIMD build.  A flat
+// access to LDS goes the vector-memory way round, counts in vmcnt AND lgkmcnt and returns out of order, so every use
+// waits for `vmcnt(0) lgkmcnt(0)`: each LDS look-up drained every global load in flight.  Here every pointer carries its
+// address space in its type: Gp<T> = global (the worker slabs, the shared clause database, the exchange ring),
+// LdsI32 / LdsU32 = LDS.  The host-side emulator build (tests/emu) has one address space: the qualifiers vanish.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MS_LDS __attribute__((address_space(3)))
+#define MS_GLB __attribute__((address_space(1)))
+#else
+#define MS_LDS
+#define MS_GLB
+#endif
+template <class T> using Gp = T MS_GLB*;
+template <class T> DEV T gld(Gp<const T> p) { return *p; }   // (a load as a value: `c ? *p : x` would mix address spaces)
+typedef volatile int32_t MS_LDS* LdsI32;
+typedef volatile uint32_t MS_LDS* LdsU32;
+// LDS read-modify-write (ds_or / ds_and / ds_add_rtn / ds_cmpst_rtn); the wave is the only agent that sees this memory
+DEV void lds_or(LdsU32 p, uint32_t v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+DEV void lds_and(LdsU32 p, uint32_t v) { (void)__hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+DEV uint32_t lds_add(LdsU32 p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+DEV uint32_t lds_cas(LdsU32 p, uint32_t expect, uint32_t v) {   // returns what was there
+    (void)__hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return expect;
+}
+
 struct Wk {
-    char* slab;                // this worker's private slab; arrays are at slab + L.<field>
+    Gp<char> slab;              // this worker's private slab; arrays are at slab + L.<field>
     // LDS
-    volatile int32_t* ring;
-    volatile uint32_t* claim;
-    volatile uint32_t* ov_cnt;
-    volatile uint32_t* hist;   // 64 words, reduce_db; also the scratch of flat_setup (BCP)
-    volatile uint32_t* lval;   // packed assignment, 2 bits per variable (LV variants)
-    volatile uint32_t* lseen;  // conflict analysis' "seen" marks, 1 bit per variable (LV variants; all zero between analyses)
-    volatile uint32_t* lcur;   // (LV) variables assigned at the CURRENT decision level (level > 0)
-    volatile uint32_t* lzero;  // (LV) variables assigned at level 0
-    volatile int32_t* bfl;     // the false literal of each lane group of the current BCP step
+    LdsI32 ring;
+    LdsU32 claim;
+    LdsU32 ov_cnt;
+    LdsU32 hist;   // 64 words, reduce_db; also the scratch of flat_setup (BCP)
+    LdsU32 lval;   // packed assignment, 2 bits per variable (LV variants)
+    LdsU32 lseen;  // conflict analysis' "seen" marks, 1 bit per variable (LV variants; all zero between analyses)
+    LdsU32 lcur;   // (LV) variables assigned at the CURRENT decision level (level > 0)
+    LdsU32 lzero;  // (LV) variables assigned at level 0
+    LdsI32 bfl;     // the false literal of each lane group of the current BCP step
     // hot uniform scalars
     int lane;
     int trail_n, qhead, n_levels, ring_lo;
@@ -95,8 +124,8 @@ struct Wk {
 
 // Arrays are addressed through the kernel arguments (scalar registers / scalar loads), not through
 // pointers held per worker: `sh` = shared immutable CSRs, `L` = offsets inside the private slab.
-#define WK_PTR(T, w, L, field) ((T*)((w).slab + (L).field))
-#define WKA(T, field) ((T*)(w.slab + L.field))
+#define WK_PTR(T, w, L, field) ((Gp<T>)((w).slab + (L).field))
+#define WKA(T, field) ((Gp<T>)(w.slab + L.field))
 #define VREC WKA(MsVarRec, vrec)
 #define VMPOS WKA(int32_t, vm_pos)
 
@@ -141,13 +170,13 @@ template <bool LV>
 DEV void asg_set(Wk& w, const MsShared& sh, const MsLayout& L, int lit) {  // variable currently unassigned
     const int v = lit >> 1;
     const uint32_t bits = (2u | (uint32_t)(lit & 1)) << ((v & 15) * 2);
-    if (LV) atomicOr((uint32_t*)&w.lval[v >> 4], bits);
+    if (LV) lds_or(&w.lval[v >> 4], bits);
     else __hip_atomic_fetch_or(WKA(uint32_t, val) + (v >> 4), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 template <bool LV>
 DEV void asg_clear(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
     const uint32_t mask = ~(3u << ((v & 15) * 2));
-    if (LV) atomicAnd((uint32_t*)&w.lval[v >> 4], mask);
+    if (LV) lds_and(&w.lval[v >> 4], mask);
     else __hip_atomic_fetch_and(WKA(uint32_t, val) + (v >> 4), mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -161,18 +190,22 @@ DEV bool seen_get(const Wk& w, const MsShared& sh, const MsLayout& L, int v) {
 }
 template <bool LV>
 DEV void seen_set(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
-    if (LV) atomicOr((uint32_t*)&w.lseen[v >> 5], 1u << (v & 31));
+    if (LV) lds_or(&w.lseen[v >> 5], 1u << (v & 31));
     else VREC[v].seen = 1;
 }
 template <bool LV>
 DEV void seen_clr(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
-    if (LV) atomicAnd((uint32_t*)&w.lseen[v >> 5], ~(1u << (v & 31)));
+    if (LV) lds_and(&w.lseen[v >> 5], ~(1u << (v & 31)));
     else VREC[v].seen = 0;
 }
 
-DEV void clause_range(const Wk& w, const MsShared& sh, const MsLayout& L, int c, const int32_t*& lits, int& size) {
+// where a clause's literals are: the shared store of the original long clauses, or the worker's learnt store
+DEV Gp<const int32_t> lits_base(const Wk& w, const MsShared& sh, const MsLayout& L, int c) {
+    return (uint32_t)c < sh.n_orig ? (Gp<const int32_t>)sh.cl_lits : (Gp<const int32_t>)WKA(int32_t, lc_lits);
+}
+DEV void clause_range(const Wk& w, const MsShared& sh, const MsLayout& L, int c, Gp<const int32_t>& lits, int& size) {
     const MsClauseRec h = WKA(MsClauseRec, wl)[c];
-    lits = ((uint32_t)c < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + h.start;
+    lits = lits_base(w, sh, L, c) + h.start;
     size = (int)h.size;
 }
 
@@ -186,8 +219,8 @@ DEV void ring_note_growth(Wk& w, const MsShared& sh, const MsLayout& L) {
 template <bool LV>
 DEV void level_mark(Wk& w, int v) {
     if (!LV) return;
-    if (w.n_levels == 0) atomicOr((uint32_t*)&w.lzero[v >> 5], 1u << (v & 31));
-    else atomicOr((uint32_t*)&w.lcur[v >> 5], 1u << (v & 31));
+    if (w.n_levels == 0) lds_or(&w.lzero[v >> 5], 1u << (v & 31));
+    else lds_or(&w.lcur[v >> 5], 1u << (v & 31));
 }
 DEV MsVarRec var_rec(int level, int reason, uint32_t start, uint32_t size, int lit) {
     return MsVarRec{level, reason, start, (uint16_t)(size > 0xffffu ? 0u : size), (uint8_t)(lit & 1), 0};
@@ -226,7 +259,7 @@ DEV int claim_insert(Wk& w, bool want, int q) {
     const uint32_t key = ((uint32_t)(q + 1) << 6) | (uint32_t)w.lane;
     uint32_t slot = (((uint32_t)(q >> 1) * 2654435761u) >> 20) & (MS_CLAIM_SLOTS - 1);
     for (;;) {
-        const uint32_t old = atomicCAS((uint32_t*)&w.claim[slot], 0u, key);
+        const uint32_t old = lds_cas(&w.claim[slot], 0u, key);
         if (old == 0) return CLAIM_WON;
         const uint32_t oq = (old >> 6) - 1;
         if ((oq >> 1) == (uint32_t)(q >> 1)) return oq == (uint32_t)q ? CLAIM_DUP : CLAIM_LOST;
@@ -286,8 +319,8 @@ DEV MsClauseHdr clause_hdr_of(const Wk& w, const MsShared& sh, const MsLayout& L
 // Append (cref, blocker) to the list of literal t (uniform call, rare path:
 // learnt clause attach and overflow repair).  Grows the list from the bump pool.
 DEV bool list_push_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int t, int cref, int blocker, uint32_t start, uint32_t size) {
-    MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
-    int4* pool = WKA(int4, pool);
+    Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
+    Gp<int4> pool = WKA(int4, pool);
     uint32_t s = (uint32_t)uni((int)whdr[t].size);
     uint32_t cap = (uint32_t)uni((int)whdr[t].cap);
     if (s > cap) s = cap;  // overshoot left by failed atomic pushes
@@ -311,7 +344,7 @@ DEV void repair_overflow(Wk& w, const MsShared& sh, const MsLayout& L) {
     uint32_t n = (uint32_t)uni((int)*w.ov_cnt);
     if (n == 0) return;
     wave_fence();
-    const int32_t* ov = WK_PTR(int32_t, w, L, overflow);
+    Gp<const int32_t> ov = WK_PTR(int32_t, w, L, overflow);
     for (uint32_t e = 0; e < n && w.status == MS_ST_RUNNING; e++) {
         int t = uni(ov[3 * e]), c = uni(ov[3 * e + 1]), b = uni(ov[3 * e + 2]);
         const MsClauseHdr h = clause_hdr_of(w, sh, L, c);
@@ -342,7 +375,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
     bool scanning = false, need_tail = false;
     int other = 0, vo = MS_VAL_TRUE, r = -1;
     int size = (int)ch.size;
-    const int32_t* cl = ((uint32_t)wt.x < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + ch.start;
+    Gp<const int32_t> cl = lits_base(w, sh, L, wt.x) + ch.start;
     uint32_t nl = 0;
     if (live && vbl != MS_VAL_TRUE) {
         other = (ww.x == fl) ? ww.y : ww.x;
@@ -350,7 +383,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
         int ls[MS_LANE_SCAN], vs[MS_LANE_SCAN];
 #pragma unroll
         for (int k = 0; k < MS_LANE_SCAN; k += 4) {
-            const int4 q = k < size ? *(const int4*)(cl + k) : make_int4(fl, fl, fl, fl);
+            const int4 q = k < size ? gld<int4>((Gp<const int4>)(cl + k)) : make_int4(fl, fl, fl, fl);
             ls[k] = q.x; ls[k + 1] = q.y; ls[k + 2] = q.z; ls[k + 3] = q.w;
         }
         vo = lit_value<LV>(w, sh, L, other);
@@ -380,8 +413,8 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
     for (u64 tm = ballot(need_tail); tm != 0; tm &= tm - 1) {
         const int f = first_lane(tm);
         const unsigned long long cp = (unsigned long long)cl;
-        const int32_t* clf = (const int32_t*)(((unsigned long long)(uint32_t)bcast((int)(cp >> 32), f) << 32) |
-                                              (unsigned long long)(uint32_t)bcast((int)cp, f));
+        Gp<const int32_t> clf = (Gp<const int32_t>)(((unsigned long long)(uint32_t)bcast((int)(cp >> 32), f) << 32) |
+                                                  (unsigned long long)(uint32_t)bcast((int)cp, f));
         const int szf = bcast(size, f), flf = bcast(fl, f), of = bcast(other, f);
         int found = -1;
         for (int k0 = MS_LANE_SCAN; k0 < szf && found < 0; k0 += MS_WAVE) {
@@ -396,15 +429,15 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
     // phase C (per lane): move the watch, or report unit / conflict
     if (scanning) {
         if (r >= 0) {
-            MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
-            *(int2*)&WKA(MsClauseRec, wl)[wt.x] = make_int2(other, r);
+            Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
+            *(Gp<int2>)&WKA(MsClauseRec, wl)[wt.x] = make_int2(other, r);
             const int t = r ^ 1;
             const uint32_t pos = atomicAdd(&whdr[t].size, 1u);
             const uint32_t tbase = whdr[t].base, tcap = whdr[t].cap;
             if (pos < tcap) WKA(int4, pool)[tbase + pos] = R.wt;
             else {
-                uint32_t o = atomicAdd((uint32_t*)w.ov_cnt, 1u);
-                int32_t* ov = WK_PTR(int32_t, w, L, overflow);
+                uint32_t o = lds_add(w.ov_cnt, 1u);
+                Gp<int32_t> ov = WK_PTR(int32_t, w, L, overflow);
                 ov[3 * o] = t;
                 ov[3 * o + 1] = wt.x;
                 ov[3 * o + 2] = other;
@@ -422,7 +455,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
 // lanes 0..15 scan, and afterwards lane `item` finds its (group, index) by walking the scan.  Returns
 // the total number of items.  w.hist layout: [0..16) rem, [16..32) a, [32..48) b, [48..64) inclusive scan.
 DEV int flat_setup(Wk& w, int G, int g, int sl, int rem, int a, int b) {
-    volatile uint32_t* fs = w.hist;
+    LdsU32 fs = w.hist;
     lds_fence();
     if (sl == 0) { fs[g] = (uint32_t)rem; fs[16 + g] = (uint32_t)a; fs[32 + g] = (uint32_t)b; }
     lds_fence();
@@ -436,7 +469,7 @@ DEV int flat_setup(Wk& w, int G, int g, int sl, int rem, int a, int b) {
     return (int)fs[48 + G - 1];
 }
 DEV void flat_item(const Wk& w, int G, int item, int& gg, int& idx, int& a, int& b) {
-    volatile uint32_t* fs = w.hist;
+    LdsU32 fs = w.hist;
     gg = 0;
     while (gg < G - 1 && (int)fs[48 + gg] <= item) gg++;
     idx = item - (gg ? (int)fs[48 + gg - 1] : 0);
@@ -448,10 +481,12 @@ DEV void flat_item(const Wk& w, int G, int item, int& gg, int& idx, int& a, int&
 template <bool LV>
 DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
     w.confl_kind = 0;
-    MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
-    int4* pool = WKA(int4, pool);
-    const MsClauseRec* wl = WKA(MsClauseRec, wl);
-    const int32_t* trail = WKA(int32_t, trail);
+    Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
+    Gp<int4> pool = WKA(int4, pool);
+    Gp<const MsClauseRec> wl = WKA(MsClauseRec, wl);
+    Gp<const int32_t> trail = WKA(int32_t, trail);
+    Gp<const int32_t> bin_lits = (Gp<const int32_t>)sh.bin_lits;
+    Gp<const int2> tern_pairs = (Gp<const int2>)sh.tern_pairs;
     while (w.qhead < w.trail_n && w.status == MS_ST_RUNNING) {
         PROF_DECL
         // ---- split the wave into G groups of S lanes, one queue literal per group
@@ -471,9 +506,9 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int n = (int)wh.size;
         // round trip 1: the first chunk of all three lists
         const bool act_b = (uint32_t)sl < nb, act_t = (uint32_t)sl < nt;
-        const int q0 = act_b ? sh.bin_lits[b0 + sl] : 0;
-        const int2 pr0 = act_t ? ((const int2*)sh.tern_pairs)[t0 + sl] : make_int2(0, 0);
-        const int4 wt0 = sl < n ? pool[wb + sl] : make_int4(-1, 0, 0, 0);
+        const int q0 = act_b ? bin_lits[b0 + sl] : 0;
+        const int2 pr0 = act_t ? gld<int2>(tern_pairs + (t0 + sl)) : make_int2(0, 0);
+        const int4 wt0 = sl < n ? gld<int4>(pool + (wb + sl)) : make_int4(-1, 0, 0, 0);
         w.qhead += G;
         w.c_props += (uint32_t)G;
         w.c_steps++;
@@ -488,7 +523,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int vb = act_t ? lit_value<LV>(w, sh, L, pr0.x) : MS_VAL_TRUE;
         const int vc = act_t ? lit_value<LV>(w, sh, L, pr0.y) : MS_VAL_TRUE;
         const int vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
-        const int2 ww0 = (live0 && (!LV || vbl0 != MS_VAL_TRUE)) ? *(const int2*)&wl[wt0.x] : make_int2(0, 0);
+        const int2 ww0 = (live0 && (!LV || vbl0 != MS_VAL_TRUE)) ? gld<int2>((Gp<const int2>)&wl[wt0.x]) : make_int2(0, 0);
         PROF_MARK(PF_OFF);
         // evaluate binary + ternary entries on the snapshot
         const bool cf_b = vq == MS_VAL_FALSE, want_b = vq == MS_VAL_UNDEF;
@@ -552,7 +587,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                     const bool act = item < total;
                     int gg = 0, i = 0, fb0 = 0, ffl = 0;
                     if (act) flat_item(w, G, item, gg, i, fb0, ffl);
-                    const int q = act ? sh.bin_lits[(uint32_t)fb0 + (uint32_t)S + (uint32_t)i] : 0;
+                    const int q = act ? bin_lits[(uint32_t)fb0 + (uint32_t)S + (uint32_t)i] : 0;
                     const int v = act ? lit_value<LV>(w, sh, L, q) : MS_VAL_TRUE;
                     w.c_watch += (uint32_t)popc64(ballot(act));
                     commit_implications<LV>(w, sh, L, v == MS_VAL_UNDEF, q, MS_REASON_BIN(ffl), lost);
@@ -578,7 +613,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                     int gg = 0, i = 0, ft0 = 0, ffl = 0;
                     if (act) flat_item(w, G, item, gg, i, ft0, ffl);
                     const uint32_t e = (uint32_t)ft0 + (uint32_t)S + (uint32_t)i;
-                    const int2 pr = act ? ((const int2*)sh.tern_pairs)[e] : make_int2(0, 0);
+                    const int2 pr = act ? gld<int2>(tern_pairs + e) : make_int2(0, 0);
                     const int xb = act ? lit_value<LV>(w, sh, L, pr.x) : MS_VAL_TRUE;
                     const int xc = act ? lit_value<LV>(w, sh, L, pr.y) : MS_VAL_TRUE;
                     w.c_watch += (uint32_t)popc64(ballot(act));
@@ -609,10 +644,10 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
             for (int i0 = S; i0 < n_l && !any_cf && w.status == MS_ST_RUNNING; i0 += MS_WAVE) {
                 const int i = i0 + w.lane;
                 const bool act = i < n_l;
-                const int4 wt = act ? pool[wb_l + i] : make_int4(-1, 0, 0, 0);
+                const int4 wt = act ? gld<int4>(pool + (wb_l + i)) : make_int4(-1, 0, 0, 0);
                 const bool live = act && wt.x >= 0;
                 const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
-                const int2 ww = (live && (!LV || vbl != MS_VAL_TRUE)) ? *(const int2*)&wl[wt.x] : make_int2(0, 0);
+                const int2 ww = (live && (!LV || vbl != MS_VAL_TRUE)) ? gld<int2>((Gp<const int2>)&wl[wt.x]) : make_int2(0, 0);
                 w.c_watch += (uint32_t)popc64(ballot(live));
                 LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, fl_l, gl);
                 w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
@@ -668,7 +703,7 @@ DEV void cur_level_rebuild(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int from = uni(WK_PTR(int32_t, w, L, trail_lim)[w.n_levels - 1]);
         for (int i = from + w.lane; i < w.trail_n; i += MS_WAVE) {
             const int v = WKA(int32_t, trail)[i] >> 1;
-            atomicOr((uint32_t*)&w.lcur[v >> 5], 1u << (v & 31));
+            lds_or(&w.lcur[v >> 5], 1u << (v & 31));
         }
         lds_fence();
     }
@@ -679,7 +714,7 @@ DEV void level_zero_rebuild(Wk& w, const MsShared& sh, const MsLayout& L) {
     const int to = w.n_levels > 0 ? uni(WK_PTR(int32_t, w, L, trail_lim)[0]) : w.trail_n;
     for (int i = w.lane; i < to; i += MS_WAVE) {
         const int v = WKA(int32_t, trail)[i] >> 1;
-        atomicOr((uint32_t*)&w.lzero[v >> 5], 1u << (v & 31));
+        lds_or(&w.lzero[v >> 5], 1u << (v & 31));
     }
     lds_fence();
 }
@@ -720,7 +755,7 @@ DEV void new_decision_level(Wk& w, const MsShared& sh, const MsLayout& L) {
 // index.  Later index = more recently bumped.  vm_search: every live entry above
 // it is assigned.
 DEV void vm_compact(Wk& w, const MsShared& sh, const MsLayout& L) {
-    int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
+    Gp<int32_t> vm_order = WK_PTR(int32_t, w, L, vm_order);
     int j = 0;
     for (int i0 = 0; i0 < w.vm_end; i0 += MS_WAVE) {
         int i = i0 + w.lane;
@@ -743,7 +778,7 @@ DEV void vm_compact(Wk& w, const MsShared& sh, const MsLayout& L) {
 
 template <bool LV>
 DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
-    const int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
+    Gp<const int32_t> vm_order = WK_PTR(int32_t, w, L, vm_order);
     // Every candidate costs two random lines (its record for the liveness check, its assignment word).  The next
     // unassigned variable is usually among the first few entries (the search position follows the queue front),
     // so the first probe looks at 16 candidates only and only a miss widens to the whole wave.
@@ -801,10 +836,10 @@ DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, MsVarRec* v
 
 template <bool LV>
 DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp) {
-    MsVarRec* vrec = VREC;
-    int32_t* toclear = WK_PTR(int32_t, w, L, toclear);
-    int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
-    uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
+    Gp<MsVarRec> vrec = VREC;
+    Gp<int32_t> toclear = WK_PTR(int32_t, w, L, toclear);
+    Gp<int32_t> learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
+    Gp<uint32_t> lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
     int path_c = 0, p = -1, n_out = 1, n_clear = 0;
     int index = w.trail_n - 1;
     int chunk_hi = -1, chunk_l = 0;   // cached chunk of the trail (LV)
@@ -820,9 +855,9 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     int kind = w.confl_kind, cref = w.confl_cref, ba = w.confl_a, bb = w.confl_b, bc = w.confl_c;
     for (;;) {
         if (kind == 1) {
-            const int32_t* cl;
+            Gp<const int32_t> cl;
             int size = bc;     // kind 1: (bb, bc) = the clause's literal range when known (size 0: look it up)
-            if (size > 0) cl = ((uint32_t)cref < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + (uint32_t)bb;
+            if (size > 0) cl = lits_base(w, sh, L, cref) + (uint32_t)bb;
             else clause_range(w, sh, L, cref, cl, size);
             if ((uint32_t)cref >= sh.n_orig && w.lane == 0) lc_lbd[cref - sh.n_orig] |= 0x80000000u;  // used
             for (int k0 = 0; k0 < size; k0 += MS_WAVE) {
@@ -898,13 +933,13 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
                 if (want) {
                     const int rr = c_rec.reason;
                     if (rr >= 0 && c_rec.size > 0) {
-                        const int32_t* cl = ((uint32_t)rr < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + c_rec.start;
-                        c_l0 = *(const int4*)cl;
-                        if (c_rec.size > 4) c_l1 = *(const int4*)(cl + 4);
+                        Gp<const int32_t> cl = lits_base(w, sh, L, rr) + c_rec.start;
+                        c_l0 = *(Gp<const int4>)cl;
+                        if (c_rec.size > 4) c_l1 = *(Gp<const int4>)(cl + 4);
                     } else if (rr < 0 && MS_IS_TERN_REASON(rr)) {
                         const int e = MS_TERN_REASON_ENTRY(rr);
-                        const int2 tp = ((const int2*)sh.tern_pairs)[e];
-                        c_l0 = make_int4(sh.tern_owner[e] ^ 1, tp.x, tp.y, 0);
+                        const int2 tp = ((Gp<const int2>)sh.tern_pairs)[e];
+                        c_l0 = make_int4(((Gp<const int32_t>)sh.tern_owner)[e] ^ 1, tp.x, tp.y, 0);
                     }
                     c_ok = true;
                 }
@@ -937,8 +972,8 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
         if (r >= 0) { kind = 1; cref = r; bb = uni((int)pr.start); bc = uni((int)pr.size); }
         else if (MS_IS_TERN_REASON(r)) {
             const int e = MS_TERN_REASON_ENTRY(r);
-            const int2 pr = ((const int2*)sh.tern_pairs)[e];
-            kind = 3; ba = uni(sh.tern_owner[e]) ^ 1; bb = uni(pr.x); bc = uni(pr.y);
+            const int2 pr = ((Gp<const int2>)sh.tern_pairs)[e];
+            kind = 3; ba = uni(((Gp<const int32_t>)sh.tern_owner)[e]) ^ 1; bb = uni(pr.x); bc = uni(pr.y);
         }
         else if (MS_IS_BIN_REASON(r)) { kind = 2; ba = p; bb = MS_BIN_REASON_LIT(r); }
         else { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
@@ -965,21 +1000,21 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
                 return seen_get<LV>(w, sh, L, lv) || VREC[lv].level == 0;
             };
             if (r >= 0) {
-                const int32_t* cl;
+                Gp<const int32_t> cl;
                 int size = (int)qr.size;
-                if (size > 0) cl = ((uint32_t)r < sh.n_orig ? sh.cl_lits : WKA(int32_t, lc_lits)) + qr.start;
+                if (size > 0) cl = lits_base(w, sh, L, r) + qr.start;
                 else clause_range(w, sh, L, r, cl, size);
                 bool red = true;
                 for (int k = 0; k < size && red; k += 4) {
-                    const int4 q4 = *(const int4*)(cl + k);
+                    const int4 q4 = *(Gp<const int4>)(cl + k);
                     red = implied(q4.x) && (k + 1 >= size || implied(q4.y)) && (k + 2 >= size || implied(q4.z)) &&
                           (k + 3 >= size || implied(q4.w));
                 }
                 keep = !red;
             } else if (MS_IS_TERN_REASON(r)) {
                 const int e = MS_TERN_REASON_ENTRY(r);
-                const int2 pr = ((const int2*)sh.tern_pairs)[e];
-                keep = !(implied(sh.tern_owner[e] ^ 1) && implied(pr.x) && implied(pr.y));
+                const int2 pr = ((Gp<const int2>)sh.tern_pairs)[e];
+                keep = !(implied(((Gp<const int32_t>)sh.tern_owner)[e] ^ 1) && implied(pr.x) && implied(pr.y));
             } else if (MS_IS_BIN_REASON(r)) {
                 keep = !implied(MS_BIN_REASON_LIT(r));
             }
@@ -1013,7 +1048,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     // ---- LBD: number of distinct decision levels
     uint32_t lbd = 0;
     {
-        uint32_t* lvl_stamp = WK_PTR(uint32_t, w, L, lvl_stamp);
+        Gp<uint32_t> lvl_stamp = WK_PTR(uint32_t, w, L, lvl_stamp);
         const uint32_t base = w.lvl_stamp_ctr;
         for (int i0 = 0; i0 < n_out; i0 += MS_WAVE) {
             int i = i0 + w.lane;
@@ -1040,7 +1075,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     // the learnt clause's variables 7-13e4, by previous queue position like this order)
     if (w.vm_end + n_clear > (int)L.vm_cap) vm_compact(w, sh, L);
     {
-        int32_t* vm_order = WK_PTR(int32_t, w, L, vm_order);
+        Gp<int32_t> vm_order = WK_PTR(int32_t, w, L, vm_order);
         for (int i = w.lane; i < n_clear; i += MS_WAVE) {
             int v = toclear[i];
             seen_clr<LV>(w, sh, L, v);
@@ -1060,9 +1095,9 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
 // per-clause watched-literal pairs (no read of the old pool): count, exclusive scan
 // over the 2*n_vars lists (wave prefix sums), fill.  Runs at a propagation fixpoint.
 DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
-    MsWatchHdr* whdr = WKA(MsWatchHdr, whdr);
-    int4* pool = WKA(int4, pool);
-    const MsClauseRec* wl = WKA(MsClauseRec, wl);
+    Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
+    Gp<int4> pool = WKA(int4, pool);
+    Gp<const MsClauseRec> wl = WKA(MsClauseRec, wl);
     const uint32_t nlist = 2 * sh.n_vars;
     const uint32_t ncl = sh.n_orig + w.n_learnts;
     for (uint32_t t = (uint32_t)w.lane; t < nlist; t += MS_WAVE) whdr[t].size = 0;
@@ -1114,17 +1149,17 @@ DEV void proof_log_deletions(Wk& w, const MsLayout& L, LoopState* pls, bool dl, 
 // LBD cut-off (histogram in LDS, no sort), breaking ties by age.
 template <bool LV>
 DEV void reduce_db(Wk& w, const MsShared& sh, const MsLayout& L, LoopState* pls = nullptr) {
-    volatile uint32_t* hist = w.hist;
-    MsClauseRec* lrec = WKA(MsClauseRec, wl) + sh.n_orig;   // records of the learnt clauses
-    uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
-    int32_t* lc_lits = WK_PTR(int32_t, w, L, lc_lits);
-    uint32_t* remap = WK_PTR(uint32_t, w, L, remap);
+    LdsU32 hist = w.hist;
+    Gp<MsClauseRec> lrec = WKA(MsClauseRec, wl) + sh.n_orig;   // records of the learnt clauses
+    Gp<uint32_t> lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
+    Gp<int32_t> lc_lits = WK_PTR(int32_t, w, L, lc_lits);
+    Gp<uint32_t> remap = WK_PTR(uint32_t, w, L, remap);
     const uint32_t n = w.n_learnts;
     hist[w.lane] = 0;
     lds_fence();
     for (uint32_t k = (uint32_t)w.lane; k < n; k += MS_WAVE) {
         uint32_t l = lc_lbd[k] & MS_LBD_MASK;
-        atomicAdd((uint32_t*)&hist[l > 63 ? 63 : l], 1u);
+        lds_add(&hist[l > 63 ? 63 : l], 1u);
     }
     lds_fence();
     // cut: smallest c such that #(lbd > c) <= n/2
@@ -1236,8 +1271,8 @@ DEV int add_learnt(Wk& w, const MsShared& sh, const MsLayout& L, int n, uint32_t
             return -1;
         }
     }
-    const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
-    int32_t* lc_lits = WK_PTR(int32_t, w, L, lc_lits);
+    Gp<const int32_t> learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
+    Gp<int32_t> lc_lits = WK_PTR(int32_t, w, L, lc_lits);
     const uint32_t k = w.n_learnts, o = w.lc_lits_n;
     for (int i = w.lane; i < n; i += MS_WAVE) lc_lits[o + i] = learnt_buf[i];
     const int l0 = uni(learnt_buf[0]), l1 = uni(learnt_buf[1]);
@@ -1261,7 +1296,7 @@ DEV unsigned long long uni64(unsigned long long v) {
     return ((unsigned long long)(uint32_t)uni((int)(v >> 32)) << 32) | (unsigned long long)(uint32_t)uni((int)v);
 }
 DEV void wk_uniformize(Wk& w) {
-    w.slab = (char*)uni64((unsigned long long)w.slab);
+    w.slab = (Gp<char>)uni64((unsigned long long)w.slab);
     w.trail_n = uni(w.trail_n); w.qhead = uni(w.qhead); w.n_levels = uni(w.n_levels); w.ring_lo = uni(w.ring_lo);
     w.vm_end = uni(w.vm_end); w.vm_search = uni(w.vm_search);
     w.n_learnts = (uint32_t)uni((int)w.n_learnts); w.lc_lits_n = (uint32_t)uni((int)w.lc_lits_n);
@@ -1277,8 +1312,8 @@ DEV void wk_uniformize(Wk& w) {
 // ---- worker load / store -------------------------------------------------------
 template <bool LV>
 DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const MsParams& prm) {
-    w.slab = slab;
-    const MsState* s = WKA(MsState, state);
+    w.slab = (Gp<char>)slab;
+    Gp<const MsState> s = WKA(MsState, state);
     w.trail_n = s->trail_n; w.qhead = s->qhead; w.n_levels = s->n_levels;
     w.vm_end = s->vm_end; w.vm_search = s->vm_search;
     w.n_learnts = s->n_learnts; w.lc_lits_n = s->lc_lits_n; w.pool_top = s->pool_top;
@@ -1292,7 +1327,7 @@ DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const
     for (int i = 0; i <= PF_N; i++) w.prof[i] = 0;
 #endif
     if (LV) {  // stage the packed assignment words in LDS for this slice
-        const uint32_t* gv = WKA(uint32_t, val);
+        Gp<const uint32_t> gv = WKA(uint32_t, val);
         const uint32_t words = (sh.n_vars + 15) >> 4;
         for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) w.lval[i] = gv[i];
     }
@@ -1303,12 +1338,12 @@ DEV void wk_store(Wk& w, const MsShared& sh, const MsLayout& L, u64 cycles) {
     u64 cl = wave_sum_u32(w.c_cl_lit);
     lds_fence();
     if (LV) {
-        uint32_t* gv = WKA(uint32_t, val);
+        Gp<uint32_t> gv = WKA(uint32_t, val);
         const uint32_t words = (sh.n_vars + 15) >> 4;
         for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) gv[i] = w.lval[i];
     }
     if (w.lane == 0) {
-        MsState* s = WKA(MsState, state);
+        Gp<MsState> s = WKA(MsState, state);
         s->trail_n = w.trail_n; s->qhead = w.qhead; s->n_levels = w.n_levels;
         s->vm_end = w.vm_end; s->vm_search = w.vm_search;
         s->n_learnts = w.n_learnts; s->lc_lits_n = w.lc_lits_n; s->pool_top = w.pool_top;
@@ -1332,12 +1367,12 @@ struct LoopState {
     uint32_t lbdq_n, lbdq_i;
     double trail_avg;
     int n_assumps;
-    volatile uint32_t* lbdq;   // LDS ring of the last MS_LBDQ learnt-clause LBDs
-    int32_t* proof_buf;        // DRUP log (worker 0 only) or nullptr
-    uint32_t* proof_len;
+    LdsU32 lbdq;               // LDS ring of the last MS_LBDQ learnt-clause LBDs
+    Gp<int32_t> proof_buf;     // DRUP log of this worker, or nullptr
+    Gp<uint32_t> proof_len;
     uint32_t proof_cap;
     // clause exchange (share_pool == nullptr: off)
-    const int4* share_pool;
+    Gp<const int4> share_pool;
     u64 share_n, share_pos, n_exported, n_imported, n_imported_units, last_import_confl;
     uint32_t share_slots, share_max_lbd, share_max_len, share_interval, exp_n, wid;
     // best-phase rephasing (CaDiCaL's "rephase to best"): the polarities of the longest conflict-free assignment seen
@@ -1363,8 +1398,8 @@ DEV void proof_log_deletions(Wk& w, const MsLayout& L, LoopState* pls, bool dl, 
     }
     const uint32_t total = (uint32_t)bcast((int)incl, 63), base = (uint32_t)uni((int)*pls->proof_len);
     if (base + total <= pls->proof_cap && dl) {
-        int32_t* out = pls->proof_buf + base + (incl - need);
-        const int32_t* lits = WK_PTR(int32_t, w, L, lc_lits) + o0;
+        Gp<int32_t> out = pls->proof_buf + base + (incl - need);
+        Gp<const int32_t> lits = WK_PTR(int32_t, w, L, lc_lits) + o0;
         out[0] = -2;
         for (uint32_t j = 0; j < len; j++) out[1 + j] = lits[j];
         out[1 + len] = -1;
@@ -1382,10 +1417,10 @@ DEV void ls_uniformize(LoopState& ls) {
     ls.lbdq_n = (uint32_t)uni((int)ls.lbdq_n); ls.lbdq_i = (uint32_t)uni((int)ls.lbdq_i);
     ls.trail_avg = __longlong_as_double((long long)uni64((u64)__double_as_longlong(ls.trail_avg)));
     ls.n_assumps = uni(ls.n_assumps);
-    ls.lbdq = (volatile uint32_t*)uni64((u64)ls.lbdq);
-    ls.proof_buf = (int32_t*)uni64((u64)ls.proof_buf); ls.proof_len = (uint32_t*)uni64((u64)ls.proof_len);
+    ls.lbdq = (LdsU32)uni64((u64)ls.lbdq);
+    ls.proof_buf = (Gp<int32_t>)uni64((u64)ls.proof_buf); ls.proof_len = (Gp<uint32_t>)uni64((u64)ls.proof_len);
     ls.proof_cap = (uint32_t)uni((int)ls.proof_cap);
-    ls.share_pool = (const int4*)uni64((u64)ls.share_pool);
+    ls.share_pool = (Gp<const int4>)uni64((u64)ls.share_pool);
     ls.share_n = uni64(ls.share_n); ls.share_pos = uni64(ls.share_pos); ls.n_exported = uni64(ls.n_exported);
     ls.n_imported = uni64(ls.n_imported); ls.n_imported_units = uni64(ls.n_imported_units);
     ls.last_import_confl = uni64(ls.last_import_confl);
@@ -1409,8 +1444,8 @@ DEV void import_shared(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& 
     u64 pos = ls.share_pos;
     const u64 end = ls.share_n;
     if (end - pos > ls.share_slots) pos = end - ls.share_slots;   // the ring overwrote what we never read
-    int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
-    const int32_t* pool = (const int32_t*)ls.share_pool;
+    Gp<int32_t> learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
+    Gp<const int32_t> pool = (Gp<const int32_t>)ls.share_pool;
     int budget = 4096;   // records per call; the rest waits for the next restart
     for (; pos < end && budget > 0 && w.status == MS_ST_RUNNING; pos++, budget--) {
         // one record per step, one literal per lane (records are 128 bytes: one coalesced load)
@@ -1458,7 +1493,7 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         const int lim = uni(WK_PTR(int32_t, w, L, trail_lim)[w.n_levels - 1]);
         if (lim > ls.best_trail) {
             ls.best_trail = lim;
-            uint8_t* best = WK_PTR(uint8_t, w, L, best);
+            Gp<uint8_t> best = WK_PTR(uint8_t, w, L, best);
             for (int i = w.lane; i < lim; i += MS_WAVE) {
                 const int l = WKA(int32_t, trail)[i];
                 best[l >> 1] = (uint8_t)(l & 1);
@@ -1468,7 +1503,7 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     Learnt lr = analyze<LV>(w, sh, L, (uint32_t)(ls.conflicts & 0x3fffu));
     PROF_MARK(PF_ANALYZE);
     if (w.status != MS_ST_RUNNING) return false;
-    const int32_t* learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
+    Gp<const int32_t> learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
     if (ls.proof_buf) {   // DRUP: every learnt clause, in derivation order
         const uint32_t o = *ls.proof_len;
         if (o + (uint32_t)lr.n + 1 <= ls.proof_cap) {
@@ -1485,7 +1520,7 @@ DEV bool on_conflict_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
     bool exported = false;
     if (ls.share_pool && lr.n <= (int)ls.share_max_len && (lr.n <= MS_SHARE_SMALL || lr.lbd <= ls.share_max_lbd) && ls.exp_n < MS_EXPORT_RECS) {
         exported = true;
-        int32_t* rec = WK_PTR(int32_t, w, L, exp) + ls.exp_n * MS_SHARE_REC;
+        Gp<int32_t> rec = WK_PTR(int32_t, w, L, exp) + ls.exp_n * MS_SHARE_REC;
         if (w.lane <= lr.n)
             rec[w.lane] = w.lane == 0 ? (int)((uint32_t)lr.n | ((lr.lbd > 255u ? 255u : lr.lbd) << 6) | (ls.wid << 14))
                                       : learnt_buf[w.lane - 1];
@@ -1560,9 +1595,9 @@ DEV_COLD bool on_conflict(Wk& wr, const MsShared& shr, const MsLayout& Lr, LoopS
 // One literal per lane, so clauses of up to 64 literals.  Returns true if a clause changed.
 template <bool LV>
 DEV bool vivify_pass(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls) {
-    MsClauseRec* lrec = WKA(MsClauseRec, wl) + sh.n_orig;
-    uint32_t* lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
-    int32_t* lc_lits = WK_PTR(int32_t, w, L, lc_lits);
+    Gp<MsClauseRec> lrec = WKA(MsClauseRec, wl) + sh.n_orig;
+    Gp<uint32_t> lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
+    Gp<int32_t> lc_lits = WK_PTR(int32_t, w, L, lc_lits);
     bool changed = false;
     uint32_t done = 0;
     for (int k = (int)w.n_learnts - 1; k >= 0 && done < ls.vivify && w.status == MS_ST_RUNNING && w.qhead == w.trail_n; k--) {
@@ -1623,7 +1658,7 @@ DEV bool vivify_pass(Wk& w, const MsShared& sh, const MsLayout& L, LoopState& ls
         if (lbd > (uint32_t)n_new - 1) lbd = (uint32_t)n_new - 1;
         bool exported = (raw & MS_LBD_NOLOG) != 0;
         if (!exported && ls.share_pool && n_new <= (int)ls.share_max_len && (n_new <= MS_SHARE_SMALL || lbd <= ls.share_max_lbd) && ls.exp_n < MS_EXPORT_RECS) {
-            int32_t* rec = WK_PTR(int32_t, w, L, exp) + ls.exp_n * MS_SHARE_REC;
+            Gp<int32_t> rec = WK_PTR(int32_t, w, L, exp) + ls.exp_n * MS_SHARE_REC;
             if (w.lane == 0) rec[0] = (int)((uint32_t)n_new | ((lbd > 255u ? 255u : lbd) << 6) | (ls.wid << 14));
             if (mine) rec[1 + rank] = lit;
             ls.exp_n++;
@@ -1652,7 +1687,7 @@ DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         ls.restarts++;
         cancel_until<LV>(w, sh, L, 0);
         if (ls.rephase && ls.conflicts >= ls.next_rephase) {
-            const uint8_t* best = WK_PTR(uint8_t, w, L, best);
+            Gp<const uint8_t> best = WK_PTR(uint8_t, w, L, best);
             for (uint32_t v = (uint32_t)w.lane; v < sh.n_vars; v += MS_WAVE) {
                 const uint8_t b = best[v];
                 if (b != 255) VREC[v].phase = b;
@@ -1684,7 +1719,7 @@ DEV void on_fixpoint_body(Wk& w, const MsShared& sh, const MsLayout& L, LoopStat
         ls.last_import_confl = ls.conflicts;
         if (w.status != MS_ST_RUNNING || w.qhead < w.trail_n) return;   // imported units: BCP first
     }
-    const int32_t* assumps = WK_PTR(int32_t, w, L, assumps);
+    Gp<const int32_t> assumps = WK_PTR(int32_t, w, L, assumps);
     int next = -1;
     while (w.n_levels < ls.n_assumps) {
         int a = uni(assumps[w.n_levels]);
@@ -1742,8 +1777,8 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
-    w.lseen = s_lval + ((sh.n_vars + 15) >> 4);   // (LV) three bitmaps behind the assignment words
+    w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl;
+    w.lseen = w.lval + ((sh.n_vars + 15) >> 4);   // (LV) three bitmaps behind the assignment words
     w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);
     w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
     if (w.lane == 0) s_ov = 0;
@@ -1751,7 +1786,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     wk_uniformize(w);
     if (LV) { level_zero_rebuild(w, sh, L); cur_level_rebuild(w, sh, L); }
-    MsState* st = WKA(MsState, state);
+    Gp<MsState> st = WKA(MsState, state);
     if (w.lane < MS_LBDQ) s_lbdq[w.lane] = st->lbdq[w.lane];
     lds_fence();
     const u64 t0 = __builtin_readcyclecounter();
@@ -1760,12 +1795,12 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     ls.lbdq_sum = st->lbdq_sum; ls.lbd_total = st->lbd_total; ls.next_reduce = st->next_reduce;
     ls.learnt_total = st->learnt_total; ls.learnt_lits_total = st->learnt_lits_total;
     ls.lbdq_n = st->lbdq_n; ls.lbdq_i = st->lbdq_i; ls.trail_avg = st->trail_avg;
-    ls.n_assumps = st->n_assumps; ls.lbdq = s_lbdq;
+    ls.n_assumps = st->n_assumps; ls.lbdq = (LdsU32)s_lbdq;
     // DRUP: every worker logs the clauses it learns into its own buffer; the host drains all of them after each slice
-    ls.proof_buf = prm.proof_buf ? prm.proof_buf + (size_t)wid * prm.proof_cap : nullptr;
-    ls.proof_len = prm.proof_len + wid; ls.proof_cap = prm.proof_cap;
-    ls.share_pool = (const int4*)prm.share_pool;
-    ls.share_n = prm.share_pool ? *prm.share_n : 0;
+    ls.proof_buf = prm.proof_buf ? (Gp<int32_t>)prm.proof_buf + (size_t)wid * prm.proof_cap : nullptr;
+    ls.proof_len = (Gp<uint32_t>)prm.proof_len + wid; ls.proof_cap = prm.proof_cap;
+    ls.share_pool = (Gp<const int4>)prm.share_pool;
+    ls.share_n = prm.share_pool ? *(Gp<const unsigned long long>)prm.share_n : 0;
     ls.share_pos = st->share_pos; ls.n_exported = st->n_exported; ls.n_imported = st->n_imported;
     ls.n_imported_units = st->n_imported_units; ls.last_import_confl = st->last_import_confl;
     ls.share_slots = prm.share_slots; ls.share_max_lbd = prm.share_max_lbd; ls.share_interval = prm.share_interval;
@@ -1814,8 +1849,8 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
             if (slice_confl >= prm.slice_conflicts) break;
             if ((slice_confl & 63) == 0) {
                 // one answer per wave (another thread / workgroup may write these while the wave reads them)
-                if (uni(*prm.stop_flag)) break;
-                if (prm.stop_on_any && uni(*(volatile int32_t*)prm.any_done)) break;
+                if (uni(*(Gp<const volatile int32_t>)prm.stop_flag)) break;
+                if (prm.stop_on_any && uni(*(Gp<const volatile int32_t>)prm.any_done)) break;
             }
         } else {
             if (w.status != MS_ST_RUNNING) break;
@@ -1851,8 +1886,8 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
         // offer the oldest free decisions for cube splitting (host-side work stealing)
         int ns = 0;
         if (w.status == MS_ST_RUNNING) {
-            const int32_t* tl = WK_PTR(int32_t, w, L, trail_lim);
-            const int32_t* tr = WKA(int32_t, trail);
+            Gp<const int32_t> tl = WK_PTR(int32_t, w, L, trail_lim);
+            Gp<const int32_t> tr = WKA(int32_t, trail);
             for (int lv = ls.n_assumps; lv < w.n_levels && ns < MS_SPLIT_MAX; lv++) st->split[ns++] = tr[tl[lv]];
         }
         st->n_split = ns;
@@ -1885,8 +1920,8 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
-    w.lseen = s_lval + ((sh.n_vars + 15) >> 4);   // (no analysis in this kernel; the level bitmaps are still maintained)
+    w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl;
+    w.lseen = w.lval + ((sh.n_vars + 15) >> 4);   // (no analysis in this kernel; the level bitmaps are still maintained)
     w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);
     w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
     if (w.lane == 0) s_ov = 0;
@@ -1896,7 +1931,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     lds_fence();
     const u64 t0 = __builtin_readcyclecounter();
     const int n_script = WKA(MsState, state)->n_script;
-    const int32_t* script = WK_PTR(int32_t, w, L, script);
+    Gp<const int32_t> script = WK_PTR(int32_t, w, L, script);
     bool confl = propagate<LV>(w, sh, L);
     for (int d = 0; d < n_script && !confl && w.status == MS_ST_RUNNING; d++) {
         int a = uni(script[d]);
@@ -1935,8 +1970,8 @@ __global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = s_ring; w.claim = s_claim; w.ov_cnt = &s_ov; w.hist = s_hist; w.lval = s_lval; w.bfl = s_bfl;
-    w.lseen = s_lval + ((sh.n_vars + 15) >> 4);
+    w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl;
+    w.lseen = w.lval + ((sh.n_vars + 15) >> 4);
     w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);
     w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
     if (w.lane == 0) s_ov = 0;
@@ -1946,9 +1981,9 @@ __global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout
     lds_fence();
     const u64 t0 = __builtin_readcyclecounter();
     const int n_script = WKA(MsState, state)->n_script;
-    int32_t* script = WK_PTR(int32_t, w, L, script);
-    uint32_t* stamp = WK_PTR(uint32_t, w, L, lvl_stamp);     // per variable: (probe index + 1) << 1 | sign of the implied literal
-    int32_t* facts = WK_PTR(int32_t, w, L, toclear);
+    Gp<int32_t> script = WK_PTR(int32_t, w, L, script);
+    Gp<uint32_t> stamp = WK_PTR(uint32_t, w, L, lvl_stamp);     // per variable: (probe index + 1) << 1 | sign of the implied literal
+    Gp<int32_t> facts = WK_PTR(int32_t, w, L, toclear);
     const int fact_cap = ((int)sh.n_vars + 1) / 3;
     int n_facts = 0;
     bool confl = propagate<LV>(w, sh, L);      // the formula's own units (normally already at their fixpoint)
@@ -1967,7 +2002,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout
             const bool second = prev_a == (a ^ 1);
             ran = !failed;
             if (!failed) {
-                const int32_t* trail = WKA(int32_t, trail);
+                Gp<const int32_t> trail = WKA(int32_t, trail);
                 const uint32_t mine = (uint32_t)(d + 1) << 1, prev = (uint32_t)d << 1;
                 for (int i0 = base + 1; i0 < w.trail_n; i0 += MS_WAVE) {
                     const int i = i0 + w.lane;
