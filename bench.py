@@ -62,9 +62,41 @@ def measured_copy_gbs(torch, device_index):
     return best
 
 
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1) and relay rank 0's line.  This parent never touches HIP or torch.cuda."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def _build_identity():
+    """What a profile must match to be evidence about THIS build: the commit and the kernel sources' hash."""
+    import hashlib
+    import subprocess
+    h = hashlib.sha256()
+    for f in ("timberborn_support_solver_amd/csrc/device/kernels.hip.h", "timberborn_support_solver_amd/csrc/device/layout.h",
+              "timberborn_support_solver_amd/csrc/mi355sat.hip"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+    except Exception:
+        head = ""
+    return {"git_head": head or None, "kernel_source_sha16": h.hexdigest()[:16]}
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-leg":
         return _cpu_leg(sys.argv[2], sys.argv[3], sys.argv[4])
+    if len(sys.argv) >= 2 and sys.argv[1] == "--build-identity":
+        print(json.dumps(_build_identity()))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
@@ -75,7 +107,11 @@ def main():
     ap.add_argument("--workers", type=int, default=4096, help="wavefront workers per GPU (16 per CU)")
     ap.add_argument("--slice-ms", type=int, default=250, help="device time of one step (one kernel launch)")
     ap.add_argument("--cpu-conflicts", type=int, default=200000, help="conflict budget of the CPU baseline sample (~10-15 s)")
-    ap.add_argument("--first-unsat-size", type=int, default=24, help="rect size of the wall-clock-to-first-UNSAT rung (0 = skip)")
+    ap.add_argument("--first-unsat-sizes", default="24,26,28", help="rect sizes of the wall-clock-to-first-UNSAT ladders, each run by "
+                    "the GPU loop and by the CPU restatement's loop in this same run ('' or 0 = skip); first_unsat_wall_clock_s is "
+                    "the largest size's")
+    ap.add_argument("--first-unsat-size", type=int, default=None, help="(old form) one size; 0 = skip")
+    ap.add_argument("--first-unsat-limit", type=float, default=150.0, help="time limit per ladder and side, seconds")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the all-cores CPU leg (0 = the cores this process may use, at most 16)")
     ap.add_argument("--var-order", type=int, default=0, help="0 caller's numbering (default), 1 locality order (A/B)")
@@ -84,6 +120,11 @@ def main():
                     "runs the product default (exchange on).")
     ap.add_argument("--platforms", default="default", choices=["default", "1x1"])
     args = ap.parse_args()
+    if args.first_unsat_size is not None:
+        args.first_unsat_sizes = str(args.first_unsat_size)
+    fu_sizes = [int(x) for x in args.first_unsat_sizes.split(",") if x.strip() and int(x) > 0]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(args.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -163,6 +204,7 @@ def main():
     n_win = 3 if args.steps >= 3 else 1
     edges = [round(i * args.steps / n_win) for i in range(n_win + 1)]
     win = [(marks[b][1] - marks[a][1]) / max(marks[b][0] - marks[a][0], 1e-9) for a, b in zip(edges[:-1], edges[1:])]
+    per_step = [round((marks[i + 1][1] - marks[i][1]) / max(marks[i + 1][0] - marks[i][0], 1e-9) / 1e9, 3) for i in range(args.steps)]
 
     d = {k: st1[k] - st0[k] for k in ("propagations", "conflicts", "decisions", "n_deq", "n_watch", "n_cl_lit",
                                       "n_move", "n_enq", "kernel_seconds", "kernel_launches")}
@@ -234,17 +276,19 @@ def main():
     # sequential loop (k := count - 1) on the oracle.
     first_unsat = None
     sharded = None
-    if world > 1 and args.first_unsat_size > 0:
+    if world > 1 and fu_sizes:
         # strong scaling of ONE ladder over the ranks: the bounds k = k_hi - rank - i*world are sharded, the cut
-        # (min SAT count, max UNSAT k) and the best model are the only things exchanged
+        # (min SAT count, max UNSAT k) and the best model are the only things exchanged; in the replica
+        # tail (the last bounds, every rank the same bound) the ranks also pass on the clauses they learn
         from timberborn_support_solver_amd.sweep import solver_loop_sweep_sharded
-        m = args.first_unsat_size
+        m = fu_sizes[0]
         g2 = WorldGrid.rect(m, m)
         e2 = Encoding.encode(defs, g2)
         st_sh = {}
         barrier()
         tg = time.perf_counter()
-        hist = solver_loop_sweep_sharded(g2, e2, PlatformLimits({(1, 1): max(4, m * m // 24)}), out=lambda line: None, time_limit=120,
+        hist = solver_loop_sweep_sharded(g2, e2, PlatformLimits({(1, 1): max(4, m * m // 24)}), out=lambda line: None,
+                                         time_limit=args.first_unsat_limit,
                                          make_solver=lambda: Mi355Sat(device=device_index, seed=1000 + rank),
                                          device=coll_dev, stats_out=st_sh)
         barrier()
@@ -253,42 +297,49 @@ def main():
         ok = bool(sat) and hist[-1]["result"] == SolverResult.Unsat and all(h["valid"] for h in sat)
         sharded = {"instance": f"rect {m} {m} {args.platforms}, solver_loop_sweep_sharded over {world} ranks",
                    "optimum_k": sat[-1]["count"] if ok else None, "gpu_seconds": gpu_s if ok else None,
-                   "seconds_to_cut_after_first_bound": st_sh.get("seconds_to_cut")}
-    if rank == 0 and world == 1 and args.first_unsat_size > 0 and not args.no_cpu:
+                   "seconds_to_cut_after_first_bound": st_sh.get("seconds_to_cut"),
+                   "ring_records_from_other_ranks": st_sh.get("ring_imported")}
+    if rank == 0 and world == 1 and fu_sizes and not args.no_cpu:
         from oracle import oracle as ora
-        from timberborn_support_solver_amd import PlatformLayout
-        m = args.first_unsat_size
-        g2 = WorldGrid.rect(m, m)
-        e2 = Encoding.encode(defs, g2)
-        k0 = max(4, m * m // 24)
-        from timberborn_support_solver_amd import solver_loop_sweep
-        tg = time.perf_counter()
-        hist = solver_loop_sweep(g2, e2, PlatformLimits({(1, 1): k0}), out=lambda line: None, time_limit=120,
-                                 make_solver=lambda: Mi355Sat(device=device_index))
-        gpu_s = time.perf_counter() - tg
-        sat = [h for h in hist if h["result"] == SolverResult.Sat]
-        kstar = sat[-1]["count"] if sat and hist[-1]["result"] == SolverResult.Unsat and all(h["valid"] for h in sat) else None
-        # CPU: decreasing-k loop, fresh solver per k (crates/repl/src/main.rs:290-346)
-        tc = time.perf_counter()
-        k, cpu_kstar = k0, None
-        while time.perf_counter() - tc < 120:
-            ck = e2.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
-            o = ora.OracleSolver()
-            o.add_cnf(ck.lits, ck.offsets)
-            r = o.solve(conflict_budget=5_000_000)
-            if r == 20:
-                cpu_kstar = k + 1
-                break
-            if r != 10:
-                break
-            cnt = PlatformLayout.from_assignment(o.model(ck.n_vars)[:e2.n_vars], e2).platform_count()
-            k = cnt - 1
-        cpu_s = time.perf_counter() - tc
-        note(f"first UNSAT rect {m}: gpu {gpu_s:.2f} s (k* {kstar}), cpu {cpu_s:.2f} s (k* {cpu_kstar})")
-        first_unsat = {"instance": f"rect {m} {m} {args.platforms}, solver_loop_sweep from k={k0} (first bound alone, the lower bounds as one batch on the way down, the last bounds with their own CNF)", "optimum_k": kstar,
-                       "gpu_seconds": gpu_s if kstar is not None else None, "cpu_seconds": cpu_s if cpu_kstar is not None else None,
-                       "cpu_optimum_k": cpu_kstar, "cpu_kind": "port (oracle CDCL restatement, 1 core)",
-                       "note": "rect 64 64 to a proven first UNSAT is out of reach for both sides (area bound k* >= 43)"}
+        from timberborn_support_solver_amd import PlatformLayout, solver_loop_sweep
+        first_unsat = []
+        for m in fu_sizes:
+            g2 = WorldGrid.rect(m, m)
+            e2 = Encoding.encode(defs, g2)
+            k0 = max(4, m * m // 24)
+            tg = time.perf_counter()
+            hist = solver_loop_sweep(g2, e2, PlatformLimits({(1, 1): k0}), out=lambda line: None, time_limit=args.first_unsat_limit,
+                                     make_solver=lambda: Mi355Sat(device=device_index))
+            gpu_s = time.perf_counter() - tg
+            sat = [h for h in hist if h["result"] == SolverResult.Sat]
+            kstar = sat[-1]["count"] if sat and hist[-1]["result"] == SolverResult.Unsat and all(h["valid"] for h in sat) else None
+            gpu_confl = sum(int(h["stats"].get("conflicts", 0)) for h in hist if h.get("stats"))
+            # CPU: decreasing-k loop, fresh solver per k (crates/repl/src/main.rs:290-346)
+            tc = time.perf_counter()
+            k, cpu_kstar, cpu_confl = k0, None, 0
+            while time.perf_counter() - tc < args.first_unsat_limit:
+                ck = e2.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
+                o = ora.OracleSolver()
+                o.add_cnf(ck.lits, ck.offsets)
+                r = o.solve(conflict_budget=5_000_000)
+                cpu_confl += int(o.stats()["conflicts"])
+                if r == 20:
+                    cpu_kstar = k + 1
+                    break
+                if r != 10:
+                    break
+                cnt = PlatformLayout.from_assignment(o.model(ck.n_vars)[:e2.n_vars], e2).platform_count()
+                k = cnt - 1
+            cpu_s = time.perf_counter() - tc
+            note(f"first UNSAT rect {m}: gpu {gpu_s:.2f} s (k* {kstar}, {gpu_confl:.3g} conflicts), cpu {cpu_s:.2f} s (k* {cpu_kstar}, {cpu_confl:.3g} conflicts)")
+            first_unsat.append({
+                "instance": f"rect {m} {m} {args.platforms}, -l1:{k0} to the proven optimum", "optimum_k": kstar,
+                "gpu_seconds": gpu_s if kstar is not None else None, "gpu_conflicts": gpu_confl,
+                "gpu_loop": "solver_loop_sweep (first bound alone, the lower bounds as one batch on the way down, the last bounds with their own CNF), product defaults",
+                "cpu_seconds": cpu_s if cpu_kstar is not None else None, "cpu_optimum_k": cpu_kstar, "cpu_conflicts": cpu_confl,
+                "cpu_kind": "port (oracle CDCL restatement, 1 core, the reference's sequential loop)",
+                "gpu_over_cpu": (gpu_s / cpu_s) if (kstar is not None and cpu_kstar is not None) else None,
+                "time_limit_s": args.first_unsat_limit})
     if rank == 0:
         kern_s = d["kernel_seconds"]
         launches = max(1, d["kernel_launches"])
@@ -302,9 +353,14 @@ def main():
         tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
         default_cfg = (n == 64 and args.k_lo == 44 and args.k_hi == 51 and workers == 4096 and args.slice_ms == 250 and
                        args.platforms == "default" and args.share == -1 and args.var_order == 0)
-        if tfiles and default_cfg:
-            tj = json.load(open(tfiles[-1]))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/" + os.path.basename(tfiles[-1])
+        ident = _build_identity()
+        traffic_note = "no PMC summary under profiles/ was taken on this build (kernel sources differ): traffic left null"
+        for tf in reversed(tfiles):     # attach a PMC summary only if it was measured on THESE kernel sources
+            tj = json.load(open(tf))
+            if default_cfg and tj.get("kernel_source_sha16") == ident["kernel_source_sha16"]:
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/" + os.path.basename(tf)
+                traffic_note = f"PMC passes of this command on the same kernel sources (git {tj.get('git_head')}), kernel {tj.get('kernel')}"
+                break
         out = {
             "metric": "literal-propagations/sec + wall-clock to first UNSAT, 64x64 rect",
             "value": total_props / max_dt,
@@ -327,16 +383,18 @@ def main():
                                       f"first_unsat_sharded: bounds k = k_hi - rank - i*{world} of one ladder sharded (strong)"},
             "windows": {"n": len(win), "values": win, "median": sorted(win)[len(win) // 2],
                         "spread": (max(win) - min(win)) / max(sorted(win)[len(win) // 2], 1e-9),
-                        "note": "rank 0's rate in consecutive thirds of the timed region"},
+                        "per_step": per_step,
+                       "note": "rank 0's rate in consecutive thirds of the timed region; per_step: the rate of every slice"},
             "conflicts_per_s": total_confl / max_dt,
             "decided_instances": int(decided),
-            "first_unsat_wall_clock_s": first_unsat["gpu_seconds"] if first_unsat else None,
+            "first_unsat_wall_clock_s": first_unsat[-1]["gpu_seconds"] if first_unsat else None,
             "first_unsat": first_unsat,
             "first_unsat_sharded": sharded,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "peak_measured": peak_measured,
                          "peak_measured_note": "device-to-device copy of 2 GiB on this box (read + write bytes)",
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+                         "build": ident,
                          "kernel": "ms_search_kernel", "kernel_ms_avg": kern_s / launches * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "bytes_per_propagation": alg_bytes / max(1, props)},

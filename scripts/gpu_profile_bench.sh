@@ -17,10 +17,27 @@ head -3 $OUT/${TAG}_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   N=$(echo $C | tr ' ' '_' | tr 'A-Z' 'a-z')
   echo "[profile] pmc $C"
-  rocprofv3 --pmc $C --output-format csv -d $OUT/prof_${TAG}_$N -- python3 $ROOT/bench.py --no-cpu --steps 3 --warmup 1 "$@" > $OUT/${TAG}_pmc_$N.log 2>&1 || { tail -5 $OUT/${TAG}_pmc_$N.log; exit 1; }
+  rocprofv3 --pmc $C --output-format csv -d $OUT/prof_${TAG}_$N -- python3 $ROOT/bench.py --no-cpu "$@" > $OUT/${TAG}_pmc_$N.log 2>&1 || { tail -5 $OUT/${TAG}_pmc_$N.log; exit 1; }
   python3 $ROOT/scripts/summarize_pmc.py $(find $OUT/prof_${TAG}_$N -name "*counter_collection.csv") > $OUT/${TAG}_pmc_$N.json
   cat $OUT/${TAG}_pmc_$N.json
 done
+# the traffic summary bench.py attaches to its roofline - bound to the build it was measured on
+python3 - <<PY
+import csv, glob, json, subprocess
+ident = json.loads(subprocess.run(["python3", "$ROOT/bench.py", "--build-identity"], capture_output=True, text=True).stdout)
+f = json.load(open("$OUT/${TAG}_pmc_fetch_size.json"))["FETCH_SIZE"]
+w = json.load(open("$OUT/${TAG}_pmc_write_size.json"))["WRITE_SIZE"]
+names = [r["Name"] for r in csv.DictReader(open("$OUT/${TAG}_kernel_stats.csv")) if "ms_search_kernel" in r["Name"]]
+out = {"kernel": names[0] if names else None, "git_head": ident["git_head"], "kernel_source_sha16": ident["kernel_source_sha16"],
+       "command": "python3 bench.py --no-cpu $*", "launches": [f["launches"], w["launches"]],
+       "fetch_size_kb_per_launch": f["per_launch"], "write_size_kb_per_launch": w["per_launch"],
+       "hbm_bytes_per_launch": (f["per_launch"] + w["per_launch"]) * 1024,
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of the command above (all its launches of the kernel "
+                 "averaged, warm-up included); KB -> bytes x1024; counts L2<->fabric traffic, i.e. HBM plus Infinity-Cache hits; "
+                 "FETCH_SIZE calibration for this access pattern: ${TAG}_chase_calibration.txt"}
+json.dump(out, open("$OUT/${TAG}_traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
 echo "[profile] FETCH_SIZE calibration on random 64-byte lines (scripts/microbench/chase.hip)"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/chase $ROOT/scripts/microbench/chase.hip && \
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_${TAG}_chase -- /tmp/chase 8192 1024 2000 > $OUT/${TAG}_chase.log 2>&1

@@ -153,31 +153,31 @@ DEV u64 wave_sum_u32(uint32_t v) {
 }
 
 // ---- assignment ------------------------------------------------------------------
-// 2 bits per variable (bit1 assigned, bit0 sign), 16 variables per word.  LV: the words are staged in
-// LDS for the slice.  Otherwise they stay in HBM and are read / updated at L2 (agent-scope relaxed
-// atomics: loads bypass the per-CU L1, updates are fire-and-forget OR / AND), so lanes see each other's
-// assignments without any fence.
+// In the slab: one BYTE per variable (MS_ASG_*: bit1 assigned, bit0 sign), read and written with plain loads and stores.
+// The wave is the only agent that ever touches its slab and a wave's memory operations are performed in order, so
+// lanes see each other's assignments without atomics.  (Rounds 1-2 packed 2 bits per variable and updated the words
+// with agent-scope fetch_or / fetch_and and read them with agent-scope loads: on this multi-XCD part a device-scope
+// read-modify-write is not done in the XCD's L2 but leaves it as an uncached 64-byte request to the memory side, and
+// there were two of them per propagated literal - set and clear - plus an L2-bypassing load per look-up.)
+// LV: the assignment is staged in LDS for the slice, 2 bits per variable, 16 variables per word.
 template <bool LV>
 DEV int lit_value(const Wk& w, const MsShared& sh, const MsLayout& L, int lit) {  // MS_VAL_TRUE / FALSE / UNDEF
     const int v = lit >> 1;
     uint32_t x;
-    if (LV) x = w.lval[v >> 4];
-    else x = __hip_atomic_load(WKA(uint32_t, val) + (v >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    x = (x >> ((v & 15) * 2)) & 3u;
+    if (LV) x = (w.lval[v >> 4] >> ((v & 15) * 2)) & 3u;
+    else x = WKA(uint8_t, val)[v];
     return (x & 2u) ? (int)((x ^ (uint32_t)lit) & 1u) : MS_VAL_UNDEF;
 }
 template <bool LV>
 DEV void asg_set(Wk& w, const MsShared& sh, const MsLayout& L, int lit) {  // variable currently unassigned
     const int v = lit >> 1;
-    const uint32_t bits = (2u | (uint32_t)(lit & 1)) << ((v & 15) * 2);
-    if (LV) lds_or(&w.lval[v >> 4], bits);
-    else __hip_atomic_fetch_or(WKA(uint32_t, val) + (v >> 4), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LV) lds_or(&w.lval[v >> 4], (2u | (uint32_t)(lit & 1)) << ((v & 15) * 2));
+    else WKA(uint8_t, val)[v] = (uint8_t)(2u | (uint32_t)(lit & 1));
 }
 template <bool LV>
 DEV void asg_clear(Wk& w, const MsShared& sh, const MsLayout& L, int v) {
-    const uint32_t mask = ~(3u << ((v & 15) * 2));
-    if (LV) lds_and(&w.lval[v >> 4], mask);
-    else __hip_atomic_fetch_and(WKA(uint32_t, val) + (v >> 4), mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LV) lds_and(&w.lval[v >> 4], ~(3u << ((v & 15) * 2)));
+    else WKA(uint8_t, val)[v] = MS_ASG_UNDEF;
 }
 
 // ---- "seen" marks of conflict analysis ----------------------------------------------------
@@ -426,15 +426,26 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
         }
         if (w.lane == f) { r = found; nl += (uint32_t)(szf - MS_LANE_SCAN); }
     }
-    // phase C (per lane): move the watch, or report unit / conflict
+    // phase C: move the watch, or report unit / conflict.  A moved watcher is appended to the list of its new literal;
+    // lanes that append to the SAME list in this call rank themselves (a loop over the few distinct lists), so the
+    // list's size is read and written with plain accesses: no read-modify-write leaves the wave.
+    const bool push = scanning && r >= 0;
+    const int t = r ^ 1;
+    Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
+    const int4 th = push ? gld<int4>((Gp<const int4>)&whdr[t]) : make_int4(0, 0, 0, 0);   // {base, size, cap, -}
+    int rank = 0, cnt = 0;
+    for (u64 pm = ballot(push); pm != 0;) {
+        const int tf = bcast(t, first_lane(pm));
+        const u64 same = ballot(push && t == tf);
+        if (push && t == tf) { rank = popc64(same & lanemask_lt(w.lane)); cnt = popc64(same); }
+        pm &= ~same;
+    }
     if (scanning) {
         if (r >= 0) {
-            Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
             *(Gp<int2>)&WKA(MsClauseRec, wl)[wt.x] = make_int2(other, r);
-            const int t = r ^ 1;
-            const uint32_t pos = atomicAdd(&whdr[t].size, 1u);
-            const uint32_t tbase = whdr[t].base, tcap = whdr[t].cap;
-            if (pos < tcap) WKA(int4, pool)[tbase + pos] = R.wt;
+            const uint32_t tsize = (uint32_t)th.y < (uint32_t)th.z ? (uint32_t)th.y : (uint32_t)th.z;   // (overshoot left by pushes that found the list full)
+            const uint32_t pos = tsize + (uint32_t)rank;
+            if (pos < (uint32_t)th.z) WKA(int4, pool)[(uint32_t)th.x + pos] = R.wt;
             else {
                 uint32_t o = lds_add(w.ov_cnt, 1u);
                 Gp<int32_t> ov = WK_PTR(int32_t, w, L, overflow);
@@ -442,6 +453,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
                 ov[3 * o + 1] = wt.x;
                 ov[3 * o + 2] = other;
             }
+            if (rank == 0) whdr[t].size = tsize + (uint32_t)cnt;
             R.keep = false;
         } else if (vo == MS_VAL_FALSE) R.cf = true;
         else { R.want = true; R.imp = other; }
@@ -1310,6 +1322,21 @@ DEV void wk_uniformize(Wk& w) {
 }
 
 // ---- worker load / store -------------------------------------------------------
+// 16 assignment bytes of the slab <-> one LDS word of sixteen 2-bit fields
+DEV uint32_t asg_pack4(uint32_t x) {   // bytes b0..b3 (each 0..3) -> b0 | b1 << 2 | b2 << 4 | b3 << 6
+    x = (x | (x >> 6)) & 0x000f000fu;
+    return (x | (x >> 12)) & 0xffu;
+}
+DEV uint32_t asg_unpack4(uint32_t x) {  // the inverse, on the low 8 bits
+    x = (x | (x << 12)) & 0x000f000fu;
+    return (x | (x << 6)) & 0x03030303u;
+}
+DEV uint32_t asg_pack(uint4 q) { return asg_pack4(q.x) | asg_pack4(q.y) << 8 | asg_pack4(q.z) << 16 | asg_pack4(q.w) << 24; }
+DEV uint4 asg_unpack(uint32_t x) {
+    uint4 q;
+    q.x = asg_unpack4(x & 0xffu); q.y = asg_unpack4((x >> 8) & 0xffu); q.z = asg_unpack4((x >> 16) & 0xffu); q.w = asg_unpack4(x >> 24);
+    return q;
+}
 template <bool LV>
 DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const MsParams& prm) {
     w.slab = (Gp<char>)slab;
@@ -1326,10 +1353,10 @@ DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const
 #ifdef MS_PROFILE
     for (int i = 0; i <= PF_N; i++) w.prof[i] = 0;
 #endif
-    if (LV) {  // stage the packed assignment words in LDS for this slice
-        Gp<const uint32_t> gv = WKA(uint32_t, val);
+    if (LV) {  // stage the assignment in LDS for this slice: 16 bytes of the slab -> one word of 2-bit fields
+        Gp<const uint4> gv = (Gp<const uint4>)WKA(uint8_t, val);
         const uint32_t words = (sh.n_vars + 15) >> 4;
-        for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) w.lval[i] = gv[i];
+        for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) w.lval[i] = asg_pack(gv[i]);
     }
 }
 
@@ -1338,9 +1365,9 @@ DEV void wk_store(Wk& w, const MsShared& sh, const MsLayout& L, u64 cycles) {
     u64 cl = wave_sum_u32(w.c_cl_lit);
     lds_fence();
     if (LV) {
-        Gp<uint32_t> gv = WKA(uint32_t, val);
+        Gp<uint4> gv = (Gp<uint4>)WKA(uint8_t, val);
         const uint32_t words = (sh.n_vars + 15) >> 4;
-        for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) gv[i] = w.lval[i];
+        for (uint32_t i = (uint32_t)w.lane; i < words; i += MS_WAVE) gv[i] = asg_unpack(w.lval[i]);
     }
     if (w.lane == 0) {
         Gp<MsState> s = WKA(MsState, state);

@@ -37,7 +37,7 @@
 #define MS_VAL_TRUE 0
 #define MS_VAL_FALSE 1
 #define MS_VAL_UNDEF 2
-// stored assignment per variable (a byte in HBM, 2 bits in LDS): bit1 = assigned, bit0 = sign
+// stored assignment per variable (a byte in the slab, 2 bits in LDS): bit1 = assigned, bit0 = sign
 #define MS_ASG_UNDEF 0
 #define MS_ASG_TRUE 2
 #define MS_ASG_FALSE 3
@@ -100,8 +100,8 @@ struct MsShared {
 struct MsLayout {
     uint64_t slab_bytes;
     uint64_t state;       // MsState
-    uint64_t val;         // uint32 [(n_vars+15)/16]  assignment, 2 bits per variable (MS_ASG_*): the whole
-                          //        assignment of a worker is 24 KB at 64x64, so all workers' fit in L2 + Infinity Cache
+    uint64_t val;         // uint8 [n_vars, padded to 16]  assignment, one byte per variable (MS_ASG_*), plain loads / stores;
+                          //        the LDS builds stage it as 2 bits per variable for the slice
     uint64_t vrec;        // MsVarRec [n_vars]  level, reason (+ its literal range), saved phase, seen mark
     uint64_t vm_pos;      // int32  [n_vars]  position of the variable's live entry in vm_order
     uint64_t best;        // uint8  [n_vars]  polarity of the variable in the longest conflict-free assignment seen (255: none)

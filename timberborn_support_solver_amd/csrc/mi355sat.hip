@@ -670,7 +670,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     size_t off = 0;
     auto place = [&](uint64_t& field, size_t bytes) { field = off; off = align_up(off + bytes, 256); };
     place(L.state, sizeof(MsState));
-    place(L.val, 4 * (((size_t)nv + 15) / 16));
+    place(L.val, 16 * (((size_t)nv + 15) / 16));
     place(L.vrec, sizeof(MsVarRec) * (size_t)nv);
     place(L.vm_pos, 4 * (size_t)nv);
     place(L.best, (size_t)nv);
@@ -710,7 +710,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     st->next_rephase = 2000;
     st->next_vivify = 1500;   // (easy bounds are decided before that: vivification is for the long refutations)
     memset(T + L.best, 255, nv);
-    uint32_t* val = (uint32_t*)(T + L.val);      // zero = every variable unassigned
+    uint8_t* val = (uint8_t*)(T + L.val);        // zero = every variable unassigned
     MsVarRec* vrec = (MsVarRec*)(T + L.vrec);
     int32_t* vm_order = (int32_t*)(T + L.vm_order);
     // initial decision order: the caller's numbering (the search starts at position nv - 1); variables that occur in no
@@ -733,7 +733,7 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     for (size_t i = 0; i < P.units.size(); i++) {
         int32_t l = P.units[i];
         trail[i] = l;
-        val[(l >> 1) >> 4] |= (2u | (uint32_t)(l & 1)) << (((l >> 1) & 15) * 2);
+        val[l >> 1] = (uint8_t)(2u | (uint32_t)(l & 1));
     }
     MsClauseRec* wl = (MsClauseRec*)(T + L.wl);
     MsWatchHdr* whdr = (MsWatchHdr*)(T + L.whdr);
@@ -1353,17 +1353,15 @@ void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
     }
 }
 
-inline uint8_t asg_of(const uint32_t* words, uint64_t v) { return (uint8_t)((words[v >> 4] >> ((v & 15) * 2)) & 3u); }
 
 void fetch_model(mi355sat& s, uint32_t worker, std::vector<int8_t>& out, uint64_t n_vars_out) {
-    std::vector<uint32_t> words(((size_t)s.n_vars + 15) / 16 + 1);
+    std::vector<uint8_t> asg((size_t)s.n_vars + 1);
     if (s.n_vars)
-        HIPCHK(hipMemcpy(words.data(), s.d_slabs.p + (size_t)worker * s.L.slab_bytes + s.L.val,
-                         4 * (((size_t)s.n_vars + 15) / 16), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(asg.data(), s.d_slabs.p + (size_t)worker * s.L.slab_bytes + s.L.val, s.n_vars, hipMemcpyDeviceToHost));
     // the device's values, then the eliminated variables (their kept clauses mention device variables and variables
     // eliminated later only), then the variables replaced by an equivalent literal (representatives have smaller indices)
     std::vector<int8_t> m(s.n_vars, 0);
-    for (uint64_t v = 0; v < s.n_vars; v++) m[v] = asg_of(words.data(), s.perm[v]) == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
+    for (uint64_t v = 0; v < s.n_vars; v++) m[v] = asg[s.perm[v]] == MS_ASG_TRUE ? 1 : -1;  // (a variable left free would read false)
     extend_model(s.elims, s.elim_lits, m);
     for (uint64_t v = 0; v < s.n_vars; v++) {
         const int32_t r = v < s.subst.size() ? s.subst[v] : 2 * (int32_t)v;
@@ -2139,14 +2137,14 @@ int mi355sat_propagate_batch(mi355sat* s, const int32_t* decisions, const uint64
             }
         }
         if (out_values) {
-            const size_t nw = ((size_t)P.n_vars + 15) / 16;
-            std::vector<uint32_t> raw(n_instances * nw + 1);
+            const size_t nw = P.n_vars;
+            std::vector<uint8_t> raw(n_instances * nw + 1);
             if (P.n_vars)
-                HIPCHK(hipMemcpy2D(raw.data(), 4 * nw, s->d_slabs.p + s->L.val, s->L.slab_bytes, 4 * nw,
+                HIPCHK(hipMemcpy2D(raw.data(), nw, s->d_slabs.p + s->L.val, s->L.slab_bytes, nw,
                                    n_instances, hipMemcpyDeviceToHost));
             for (uint64_t i = 0; i < n_instances; i++)
                 for (uint64_t v = 0; v < n_vars; v++) {
-                    uint8_t x = v < P.n_vars ? asg_of(raw.data() + i * nw, P.perm[v]) : MS_ASG_UNDEF;
+                    uint8_t x = v < P.n_vars ? raw[i * nw + P.perm[v]] : MS_ASG_UNDEF;
                     out_values[i * n_vars + v] = x == MS_ASG_TRUE ? 1 : (x == MS_ASG_FALSE ? -1 : 0);
                 }
         }

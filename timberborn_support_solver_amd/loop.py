@@ -103,15 +103,25 @@ def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_in
         return hist + [{"k": best - 1, "result": SolverResult.Interrupted, "count": None, "valid": None, "seconds": 0.0, "stats": {}}]
     timer = None
     interrupters = []
+    expired = []
 
     def note(i):
+        # (the limit may run out between two bounds, when the previous solver is closed and the next one not yet
+        # registered: a solver registered after the deadline is interrupted at once instead of running unlimited)
         interrupters.append(i)
+        if expired:
+            i.interrupt()
         if on_interrupter:
             on_interrupter(i)
 
+    def on_deadline():
+        expired.append(1)
+        for i in interrupters[-1:]:
+            i.interrupt()
+
     if time_limit is not None:   # the rest of the time budget holds for the sequential part as a whole
         import threading
-        timer = threading.Timer(max(0.0, time_limit - (time.perf_counter() - t0)), lambda: [i.interrupt() for i in interrupters[-1:]])
+        timer = threading.Timer(max(0.0, time_limit - (time.perf_counter() - t0)), on_deadline)
         timer.start()
     try:
         rest = solver_loop(grid, encoding, PlatformLimits({(1, 1): best - 1}), make_solver=make_solver, out=out, on_interrupter=note)
