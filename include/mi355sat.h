@@ -251,6 +251,19 @@ int mi355sat_stats(const mi355sat* s, mi355sat_stats_t* out);
  * too small. */
 int mi355sat_debug_share_ring(mi355sat* s, int32_t* out, uint64_t cap_words, uint64_t* n_records);
 
+/* Clause exchange BETWEEN handles that search the SAME formula - the replicas of the sharded loop's last bounds, one
+ * handle per GPU (every rank poses the reference's next bound, crates/repl/src/main.rs:292-295, with its own
+ * seed).  Inside one handle the workers pass their short / low-LBD learnt clauses on through a ring on the device;
+ * export hands out the records that entered the ring since the last export (never one that was imported), import
+ * appends records from another handle so that this handle's workers attach them like each other's.  Wire format, in
+ * the caller's variables: [lbd >= 1, DIMACS literals ..., 0] per clause.  Every record is a consequence of the
+ * caller's formula alone (the tests prove it with the oracle), so it may be attached under any assumptions.  Both
+ * calls are made between two mi355sat_sweep_step() of a running sweep; without one (or with the exchange off) they
+ * do nothing.  export: out may be NULL to size the buffer (nothing is consumed); records that do not fit cap_words
+ * wait for the next call. */
+int mi355sat_share_export(mi355sat* s, int32_t* out, uint64_t cap_words, uint64_t* n_words, uint64_t* n_records);
+int mi355sat_share_import(mi355sat* s, const int32_t* clauses, uint64_t n_words, uint64_t* n_records /* may be NULL */);
+
 /* Optional DRUP proof (text, DIMACS literals, one lemma per line, the empty clause last) of the next plain
  * solve(), in its default configuration: all workers, clause exchange on.  Order of the lines: what the
  * simplification derived, then after every kernel slice the clauses each worker learnt in it; every line is a

@@ -550,7 +550,7 @@ static int search(ora_solver* s, int64_t* budget) {
         if (confl != CREF_UNDEF) {
             s->st.conflicts++;
             if (s->st.conflicts % 5000 == 0 && s->var_decay < s->max_var_decay) s->var_decay += 0.01;
-            if (dlevel(s) == 0) return 20;
+            if (dlevel(s) == 0) { s->ok = 0; return 20; }   /* the formula itself is refuted, whatever the assumptions: later calls must say so too */
             /* trail queue + restart blocking */
             s->trailq_sum += (uint32_t)s->trail_n;
             if (s->trailq_n == 5000) s->trailq_sum -= s->trailq[s->trailq_i]; else s->trailq_n++;

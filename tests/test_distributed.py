@@ -109,3 +109,60 @@ def test_two_rank_sharded_sweep_with_real_solves_gloo(terrain, pset, k0, kstar, 
     enc = Encoding.encode(platform_defs(pset), grid)
     lay = PlatformLayout.from_assignment(np.asarray(m0, dtype=np.int8), enc)
     assert lay.platform_count() == kstar and lay.validate(grid).is_valid()
+
+
+def _ring_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import assert_ring_records_are_implied, emu_lib, make_grid, platform_defs
+    from timberborn_support_solver_amd import Encoding, Mi355Sat, PlatformLimits
+    from timberborn_support_solver_amd.sweep import exchange_ring
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    # the formula (totalizer for k = 6) is satisfiable, so "implied by the formula" says something; the bound the replicas
+    # work on (k = 3, an assumption) is not: k* = 4 (golden)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 6}), sweep=True)
+    s = Mi355Sat(_lib_override=emu_lib(), workers=6, slice_conflicts=10, simp=-1, seed=500 + rank, share_lbd=8)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    s.reserve(cnf.n_vars)
+    s.sweep_begin([[-int(cnf.card_outputs[3])]])
+    sent = taken = rounds = 0
+    for _ in range(40):
+        res, _ = s.sweep_step()
+        a, b = exchange_ring(s, "cpu")
+        sent, taken, rounds = sent + a, taken + b, rounds + 1
+        done = torch.tensor([1 if (res[0].value or (sent and taken and rounds >= 3)) else 0], dtype=torch.int64)
+        dist.all_reduce(done, op=dist.ReduceOp.MIN)                    # leave together
+        if int(done[0]):
+            break
+    n_ring = assert_ring_records_are_implied(s, cnf)                   # own AND foreign records follow from the formula
+    s.sweep_end()
+    st = s.stats()
+    s.close()
+    q.put((rank, res[0].name, sent, taken, n_ring, st["shared_imported"] + st["shared_imported_units"]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_clause_exchange_between_handles_gloo():
+    """The cross-GPU ring (mi355sat_share_export / _import under sweep.exchange_ring): two replicas of one refutation
+    (rect 8x8, 1x1 supports, the bound k = 3), each a handle of its own with its own seed, hand each other what their
+    workers passed on; every record in either ring - foreign ones included - is a consequence of the formula (oracle),
+    both ranks took records of the other and their workers attached some.  (The verdict through the replica tail with the
+    ring on is the `spec = 0.0` case of the sharded-sweep test above.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, verdict, sent, taken, n_ring, imported in out:
+        assert verdict in ("Interrupted", "Unsat")
+        assert sent > 0 and taken > 0, (rank, sent, taken)
+        assert n_ring >= taken and imported > 0
+    assert out[0][2] >= out[1][3] and out[1][2] >= out[0][3]          # nobody took more than the other sent

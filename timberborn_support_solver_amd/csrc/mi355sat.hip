@@ -353,6 +353,7 @@ struct mi355sat {
     DevBuf<uint32_t> d_share_intake;
     uint32_t share_slots = 0, share_hash_n = 0;
     uint64_t share_slices = 0;
+    uint64_t share_export_pos = 0;             // ring records below this were handed out by mi355sat_share_export already
     MsShared sh{};
     MsLayout L{};
     uint32_t n_workers = 0;
@@ -769,7 +770,7 @@ void upload_formula(mi355sat& s, const Prepared& P, uint32_t assump_cap, uint32_
     s.sh.tern_owner = s.d_tern_owner.p;
     // assignment in LDS (2 bits per variable) when it still leaves room for 12 waves per CU
     // (measured on rect 64x64: 12 waves/CU with the assignment in HBM beat 6 waves/CU with it in LDS)
-    s.lds_val_bytes = ((P.n_vars + 15) / 16) * 4 + 3 * ((P.n_vars + 31) / 32) * 4;   // 2-bit assignment + three 1-bit maps (marks, current level, level 0)
+    s.lds_val_bytes = ((P.n_vars + 15) / 16) * 4 + 5 * ((P.n_vars + 31) / 32) * 4;   // 2-bit assignment + five 1-bit maps (marks, current level, level 0, minimisation: failed, queued)
     s.lds_val = s.opts.lds_val == 1 || (s.opts.lds_val == 0 && s.lds_val_bytes <= 10 * 1024);
     if (s.lds_val_bytes > 150 * 1024) s.lds_val = false;
     // worker count limited by free HBM
@@ -829,6 +830,7 @@ void reset_workers(mi355sat& s) {
         HIPCHK(hipMemsetAsync(s.d_share_n.p, 0, sizeof(unsigned long long), s.stream));
         HIPCHK(hipMemsetAsync(s.d_share_hash.p, 0, sizeof(unsigned long long) * s.share_hash_n, s.stream));
         s.share_slices = 0;
+        s.share_export_pos = 0;
     }
 }
 
@@ -1414,7 +1416,7 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     bool lds = s.lds_val;
     if (mode == 0 && s.opts.lds_val == 0) {
         const uint32_t per_cu = (active + 255) / 256;
-        lds = s.lds_val_bytes <= std::min<uint32_t>(64 * 1024, 150 * 1024 / per_cu - 3 * 1024);
+        lds = s.lds_val_bytes <= std::min<uint32_t>(64 * 1024, 150 * 1024 / per_cu - 6 * 1024);   // (a workgroup's static 5.2 KB aside)
     }
     const uint32_t dyn = lds ? s.lds_val_bytes : 0;
     HIPCHK(hipEventRecord(s.ev0, s.stream));
@@ -2345,6 +2347,110 @@ int mi355sat_debug_share_ring(mi355sat* s, int32_t* out, uint64_t cap_words, uin
             (*n_records)++;
         }
         return w <= cap_words || !out ? 0 : MI355SAT_ERR_ARG;
+    } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
+    catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
+}
+
+// ---- clause exchange between handles (GPUs) working on the SAME formula ------------------------------------------------
+// Records travel as [lbd, DIMACS literals ..., 0] in the CALLER's variables: a ring record is a consequence of the
+// simplified formula this handle searches, hence of the caller's formula (simplification only derives consequences,
+// substituted variables are written as their representatives), so another handle - whose own simplification may have
+// come out differently - can map it into its own variables and attach it.
+#define MS_FOREIGN_PRODUCER 0x3ffffu    // producer id of records that came from another handle: never handed out again
+int mi355sat_share_export(mi355sat* s, int32_t* out, uint64_t cap_words, uint64_t* n_words, uint64_t* n_records) {
+    if (!s || !n_words || !n_records) return MI355SAT_ERR_ARG;
+    *n_words = 0; *n_records = 0;
+    if (!s->share_slots || !s->d_share_pool.p || !s->sweep) return 0;
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        unsigned long long n = 0;
+        HIPCHK(hipMemcpy(&n, s->d_share_n.p, sizeof n, hipMemcpyDeviceToHost));
+        uint64_t from = s->share_export_pos;
+        if (n - from > s->share_slots) from = n - s->share_slots;     // overwritten before anybody asked
+        if (n == from) return 0;
+        std::vector<int32_t> recs((size_t)(n - from) * MS_SHARE_REC);
+        for (uint64_t r = from; r < n;) {      // at most two pieces (the ring wraps)
+            const uint64_t slot = r % s->share_slots, cnt = std::min<uint64_t>(n - r, s->share_slots - slot);
+            HIPCHK(hipMemcpy(recs.data() + (r - from) * MS_SHARE_REC, s->d_share_pool.p + slot * MS_SHARE_REC,
+                             cnt * MS_SHARE_REC * sizeof(int32_t), hipMemcpyDeviceToHost));
+            r += cnt;
+        }
+        std::vector<uint32_t> inv(s->perm.size());
+        for (uint32_t e = 0; e < s->perm.size(); e++) inv[s->perm[e]] = e;
+        uint64_t w = 0, consumed = from;
+        for (uint64_t r = from; r < n; r++) {
+            const int32_t* rec = recs.data() + (r - from) * MS_SHARE_REC;
+            const uint32_t hdr = (uint32_t)rec[0];
+            const int sz = (int)(hdr & 63u);
+            if ((hdr >> 14) == MS_FOREIGN_PRODUCER || sz < 1 || sz > MS_SHARE_MAXLEN) { consumed = r + 1; continue; }
+            if (out && w + (uint64_t)sz + 2 > cap_words) break;        // the rest waits for the next call
+            if (out) {
+                out[w] = (int32_t)std::max<uint32_t>(1u, (hdr >> 6) & 255u);
+                for (int j = 1; j <= sz; j++) {
+                    if (rec[j] < 0 || (uint32_t)(rec[j] >> 1) >= inv.size()) { s->err = "literal out of range in the exchange ring"; return MI355SAT_ERR_STATE; }
+                    out[w + j] = (rec[j] & 1) ? -((int32_t)inv[rec[j] >> 1] + 1) : ((int32_t)inv[rec[j] >> 1] + 1);
+                }
+                out[w + sz + 1] = 0;
+            }
+            w += (uint64_t)sz + 2;
+            (*n_records)++;
+            consumed = r + 1;
+        }
+        if (out) s->share_export_pos = consumed;     // (out == NULL only sizes the buffer)
+        *n_words = w;
+        return 0;
+    } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
+    catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
+}
+
+int mi355sat_share_import(mi355sat* s, const int32_t* clauses, uint64_t n_words, uint64_t* n_records) {
+    if (!s || (!clauses && n_words)) return MI355SAT_ERR_ARG;
+    if (n_records) *n_records = 0;
+    if (!n_words || !s->share_slots || !s->d_share_pool.p || !s->sweep) return 0;
+    try {
+        HIPCHK(hipSetDevice(s->device));
+        std::vector<uint8_t> gone(s->n_vars, 0);       // variables this handle's simplification resolved away
+        for (const MsElim& e : s->elims) if ((uint32_t)(e.x >> 1) < gone.size()) gone[e.x >> 1] = 1;
+        std::vector<int32_t> recs;
+        uint64_t n_new = 0;
+        for (uint64_t i = 0; i < n_words;) {
+            const int32_t lbd = clauses[i++];
+            int32_t rec[MS_SHARE_REC];
+            int sz = 0;
+            bool ok = lbd >= 1;
+            while (i < n_words && clauses[i] != 0) {
+                const int32_t d = clauses[i++];
+                const uint64_t v = (uint64_t)(d < 0 ? -(int64_t)d : d);
+                if (v == 0 || v > s->n_vars || sz >= MS_SHARE_MAXLEN) { ok = false; continue; }
+                int32_t l = to_internal(d);
+                while ((size_t)(l >> 1) < s->subst.size() && s->subst[l >> 1] != 2 * (l >> 1)) l = s->subst[l >> 1] ^ (l & 1);
+                if (gone[l >> 1]) { ok = false; continue; }
+                rec[1 + sz++] = 2 * (int32_t)s->perm[l >> 1] | (l & 1);
+            }
+            if (i >= n_words) { s->err = "share_import: clause without terminator"; return MI355SAT_ERR_ARG; }
+            i++;   // the terminator
+            if (!ok || sz < 1) continue;
+            rec[0] = (int32_t)((uint32_t)sz | ((uint32_t)std::min<int32_t>(lbd, 255) << 6) | (MS_FOREIGN_PRODUCER << 14));
+            for (int j = sz + 1; j < MS_SHARE_REC; j++) rec[j] = 0;
+            recs.insert(recs.end(), rec, rec + MS_SHARE_REC);
+            n_new++;
+        }
+        if (!n_new) return 0;
+        if (n_new > s->share_slots) { s->err = "share_import: more records than the ring holds"; return MI355SAT_ERR_ARG; }
+        HIPCHK(hipStreamSynchronize(s->stream));
+        unsigned long long n = 0;
+        HIPCHK(hipMemcpy(&n, s->d_share_n.p, sizeof n, hipMemcpyDeviceToHost));
+        for (uint64_t r = 0; r < n_new;) {
+            const uint64_t slot = (n + r) % s->share_slots, cnt = std::min<uint64_t>(n_new - r, s->share_slots - slot);
+            HIPCHK(hipMemcpy(s->d_share_pool.p + slot * MS_SHARE_REC, recs.data() + r * MS_SHARE_REC,
+                             cnt * MS_SHARE_REC * sizeof(int32_t), hipMemcpyHostToDevice));
+            r += cnt;
+        }
+        n += n_new;
+        HIPCHK(hipMemcpy(s->d_share_n.p, &n, sizeof n, hipMemcpyHostToDevice));
+        if (n_records) *n_records = n_new;
+        return 0;
     } catch (HipErr& he) { s->err = he.msg; return MI355SAT_ERR_HIP; }
     catch (std::bad_alloc&) { s->err = "out of host memory"; return MI355SAT_ERR_OOM; }
 }

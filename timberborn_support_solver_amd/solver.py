@@ -99,6 +99,8 @@ def _bind(L):
     L.mi355sat_stats.argtypes = [vp, ctypes.POINTER(Mi355SatStats)]
     L.mi355sat_set_proof_path.argtypes = [vp, ctypes.c_char_p]
     L.mi355sat_debug_share_ring.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+    L.mi355sat_share_export.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.mi355sat_share_import.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
     return L
 
 
@@ -272,8 +274,25 @@ class Mi355Sat:
                 cur.append(l)
         return out
 
+    def share_export(self, max_words=1 << 20):
+        """The clauses this handle's workers passed on since the last call, for handles on OTHER GPUs that search the same
+        formula: int32 array of [lbd, DIMACS literals ..., 0] records (caller's variables); what does not fit max_words waits."""
+        buf = np.zeros(max_words, dtype=np.int32)
+        nw, nr = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._L.mi355sat_share_export(self._h, _p(buf), max_words, ctypes.byref(nw), ctypes.byref(nr)), "share_export")
+        return buf[:nw.value].copy(), nr.value
+
+    def share_import(self, records):
+        """Append records exported by another handle (share_export's format) to this handle's exchange ring; returns how
+        many were taken."""
+        records = np.ascontiguousarray(records, dtype=np.int32)
+        nr = ctypes.c_uint64(0)
+        self._check(self._L.mi355sat_share_import(self._h, _p(records), len(records), ctypes.byref(nr)), "share_import")
+        return nr.value
+
     def set_proof_path(self, path):
-        """DRUP proof of the next solve() (forces a single worker)."""
+        """DRUP proof of the next plain solve(), in its default configuration: all workers, clause exchange on (one log per
+        worker, drained after every slice)."""
         self._check(self._L.mi355sat_set_proof_path(self._h, path.encode() if path else None), "set_proof_path")
 
     def lit_val(self, lit):

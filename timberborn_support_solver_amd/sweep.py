@@ -58,6 +58,33 @@ def exchange_cut(local, model_of, n_model, device):
             "model": model, "done": min_sat < _BIG and max_unsat + 1 >= min_sat}
 
 
+def exchange_ring(solver, device, max_words=1 << 18):
+    """Cross-GPU clause exchange: every rank hands out the records its workers passed on since the last round
+    (`Mi355Sat.share_export`: [lbd, literals, 0] in the caller's variables) and attaches everybody else's
+    (`share_import`) - one all-reduce for the longest buffer, one all-gather of the padded buffers (a few hundred KB per
+    round over xGMI).  All ranks must search the same formula.  Returns (records sent, records taken)."""
+    rank, world = _world()
+    if world == 1:
+        return 0, 0
+    buf, n_sent = solver.share_export(max_words)
+    longest = torch.tensor([len(buf)], dtype=torch.int64, device=device)
+    dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+    longest = int(longest[0])
+    if longest == 0:
+        return 0, 0
+    mine = torch.zeros(longest + 1, dtype=torch.int32, device=device)
+    mine[0] = len(buf)
+    if len(buf):
+        mine[1:1 + len(buf)] = torch.as_tensor(buf, dtype=torch.int32)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    taken = 0
+    for r, t in enumerate(parts):
+        if r != rank and int(t[0]) > 0:
+            taken += solver.share_import(t[1:1 + int(t[0])].cpu().numpy())
+    return n_sent, taken
+
+
 def _bcast_first(rec, n_model, device):
     """Rank 0 made the first (loose) iteration as the reference does; everybody needs its count and model."""
     rank, world = _world()
@@ -73,7 +100,7 @@ def _bcast_first(rec, n_model, device):
 
 
 def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=print, time_limit=None, exchange_every=1,
-                              device="cpu", stats_out=None, specialize_after=2.0):
+                              device="cpu", stats_out=None, specialize_after=2.0, ring=True):
     """The decreasing-k refinement (crates/repl/src/main.rs:280-366, `-l1:K` form) sharded over the ranks of
     the default process group.  Every rank returns the same history (records shaped like
     solver_loop's: the start bound, the best layout, the refuted bound); rank 0 prints the reference's
@@ -133,6 +160,7 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
     local, looked, unsat_k = {k: ("open", None) for k in ks}, set(), -1
     t0 = time.perf_counter()
     step, interrupted, cut, specialize = 0, False, None, False
+    ring_stats = [0, 0]
     while True:
         res, _ = solver.sweep_step()
         step += 1
@@ -147,6 +175,10 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
         if step % exchange_every:
             continue
         cut = exchange_cut(local, lambda k: solver.sweep_solution_of(idx[k], n_model), n_model, device)
+        if ring:       # the ranks share one formula (one totalizer, the bounds are assumptions): their learnt clauses too
+            sent, taken = exchange_ring(solver, device)
+            ring_stats[0] += sent
+            ring_stats[1] += taken
         if cut["min_sat"] is not None and cut["min_sat"] < best_c:
             best_c, best_model = cut["min_sat"], cut["model"].clone()
         if cut["max_unsat"] is not None:
@@ -185,7 +217,7 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
     solver.close()
     if stats_out is not None:
         stats_out.update(stats=stats, seconds_to_cut=dt, seconds_total=time.perf_counter() - t_start, steps=step,
-                         rank=rank, world=world)
+                         rank=rank, world=world, ring_exported=ring_stats[0], ring_imported=ring_stats[1])
     if best_c < count0:
         lay = PlatformLayout.from_assignment(best_model.cpu().numpy().astype(np.int8), encoding)
         rec = {"k": k_hi, "result": SolverResult.Sat, "count": best_c, "valid": lay.validate(grid).is_valid(),
@@ -197,7 +229,7 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
             return history
     if specialize:
         left = None if time_limit is None else max(0.0, time_limit - dt)
-        return history + _replica_tail(grid, encoding, best_c, make_solver, say, left, device, n_model, stats_out)
+        return history + _replica_tail(grid, encoding, best_c, make_solver, say, left, device, n_model, stats_out, ring)
     if interrupted:
         history.append({"k": best_c - 1, "result": SolverResult.Interrupted, "count": None, "valid": None, "seconds": dt})
         say("Solver interrupted")
@@ -207,10 +239,12 @@ def solver_loop_sweep_sharded(grid, encoding, limits, make_solver=None, out=prin
     return history
 
 
-def _replica_tail(grid, encoding, best_c, make_solver, say, time_limit, device, n_model, stats_out):
+def _replica_tail(grid, encoding, best_c, make_solver, say, time_limit, device, n_model, stats_out, ring=True):
     """The reference's sequential loop from `best_c` on, every rank a replica with its own seed: each bound gets its own
     CNF (main.rs:292-293) and is stepped slice by slice; after every slice one all-reduce tells whether any rank has
-    the verdict, a model comes from its owner."""
+    the verdict, a model comes from its owner - and (ring) the ranks hand each other the clauses their workers passed
+    on in that slice, so that the replicas share what they learn instead of only racing (on one GPU the exchange is
+    what makes 1024 workers more than a portfolio; a plain portfolio gains nothing from more workers)."""
     rank, world = _world()
     history, t0 = [], time.perf_counter()
     while True:
@@ -231,6 +265,11 @@ def _replica_tail(grid, encoding, best_c, make_solver, say, time_limit, device, 
             verdict = int(t[0])
             if verdict or int(t[1]):
                 break
+            if ring:
+                sent, taken = exchange_ring(solver, device)
+                if stats_out is not None:
+                    stats_out["ring_exported"] = stats_out.get("ring_exported", 0) + sent
+                    stats_out["ring_imported"] = stats_out.get("ring_imported", 0) + taken
         model = torch.zeros(n_model, dtype=torch.float32, device=device)
         if verdict == SolverResult.Sat.value:
             owner = torch.tensor([rank if res[0] == SolverResult.Sat else -1], dtype=torch.int64, device=device)
