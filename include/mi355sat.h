@@ -75,7 +75,8 @@ typedef struct mi355sat_opts {
                                   (correct but, as measured in round 1, slower: DESIGN.md) */
     int32_t share;             /* learnt-clause exchange between the workers of one GPU (units, binaries and clauses of
                                   at most share_len literals with LBD <= share_lbd, passed on between kernel launches):
-                                  0 = default (on), -1 = off.  Off automatically with one worker or a proof log. */
+                                  0 = default (on), -1 = off.  Off automatically with one worker.  (A proof log keeps it on: every worker
+                                  logs what it learns, mi355sat_set_proof_path.) */
     int32_t share_lbd;         /* 0 = 4 (measured: rect 24 k=8 1.0 vs 1.3 s, rect 16 1x1 k=14 14-18 vs 24 s with 2; 6-12 no better) */
     int32_t share_len;         /* longest exchanged clause, <= 31; 0 = 31 */
     int32_t share_interval;    /* > 0: a worker with unseen exchanged clauses restarts to attach them after this many of its
@@ -89,8 +90,9 @@ typedef struct mi355sat_opts {
                                   CU, each ~3x faster than one of 16), the next 300 ms 1024, then all - easy instances
                                   are decided by one worker's few hundred conflicts; -1 = the whole fleet at once */
     int32_t one_per_simd;      /* 0 = default: a launch of at most 1024 workers (one per SIMD) runs the build of the search
-                                  kernel that owns the SIMD's whole register file (no spills, everything inlined);
-                                  -1 = always the 4-waves-per-SIMD build (A/B) */
+                                  kernel that owns the SIMD's whole register file (no spills, everything inlined), one of at
+                                  most 2048 the 2-waves-per-SIMD build, larger ones the 4-waves build;
+                                  -1 = always the 4-waves-per-SIMD build, 2 / 4 = at least the 2- / 4-waves build (A/B) */
     int32_t simp;              /* formula simplification before search (the reference's backend is `simp::Glucose`): 0 = default
                                   (on): equivalent-literal substitution, failed-literal probing on the device, subsumption and
                                   self-subsuming resolution on the device; 2 = the same plus bounded variable elimination
@@ -116,9 +118,17 @@ typedef struct mi355sat_opts {
                                   clauses of LBD <= 6 (at most 64 literals) are re-derived literal by literal under unit
                                   propagation and replaced by the shorter clause that implies them (a RUP lemma, exported like a
                                   freshly learnt clause); 0 = default 4 (measured, 1024 workers: rect 26 k = 10 37-45 s vs 46-72 s
-                                  without, rect 28 k = 11 46-54 s vs 59-80 s; 8 and 16 per pass: slower again), -1 = off */
+                                  without, rect 28 k = 11 46-54 s vs 59-80 s; 8 and 16 per pass: slower again), -1 = off.  No effect in
+                                  launches of more than 2048 workers: the full-fleet build leaves the code out */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */
+    int32_t deterministic;     /* 0 = default: time-bounded slices (all workers stop together; what a worker does in a slice, and
+                                  with it the whole trajectory, depends on timing); 1 = a reproducible mode for benchmarks and
+                                  A/B comparisons: slices are bounded by conflicts per worker (slice_conflicts, default 200), no
+                                  worker leaves a slice because another one finished, the exchanged clauses are collected in
+                                  worker order by one thread, the whole fleet runs from the first slice (no ramp-up): two runs
+                                  with the same options and seed make the same decisions and report the same counters.  Slower
+                                  (a conflict-bounded slice waits for its slowest worker). */
 } mi355sat_opts;
 
 /* Counters.  n_deq .. n_enq are the five event counters of SURVEY.md §8(d)

@@ -21,7 +21,7 @@ pub struct Opts {
     pub device: i32, pub workers: i32, pub conflict_budget: i64, pub slice_conflicts: i32, pub seed: u64,
     pub verbose: i32, pub reduce_first: i32, pub reduce_inc: i32, pub lds_val: i32, pub max_groups: i32,
     pub slice_ms: i32, pub cube_split: i32, pub share: i32, pub share_lbd: i32, pub share_len: i32,
-    pub share_interval: i32, pub var_order: i32, pub ramp: i32, pub one_per_simd: i32, pub simp: i32, pub phase_mix: i32, pub rephase: i32, pub restart_k_pct: i32, pub restart_k2_pct: i32, pub import_pct: i32, pub vivify: i32, pub rebalance: i32,
+    pub share_interval: i32, pub var_order: i32, pub ramp: i32, pub one_per_simd: i32, pub simp: i32, pub phase_mix: i32, pub rephase: i32, pub restart_k_pct: i32, pub restart_k2_pct: i32, pub import_pct: i32, pub vivify: i32, pub rebalance: i32, pub deterministic: i32,
 }
 
 /// Mirror of `mi355sat_stats_t`.

@@ -546,6 +546,30 @@ def test_emulated_sweep_priorities_and_reopening_keep_the_answers():
     s.close()
 
 
+def test_emulated_reopened_bound_without_weights_gets_a_worker():
+    """A bound withdrawn while every worker went to the other open bound, then taken up again WITHOUT weights: the
+    rebalancing must hand it a worker from the bound that has the most (round 2 left it with none and the sweep never
+    ended)."""
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 8}), sweep=True)
+    ks = [3, 2]                                                                # both refuted (k* = 4)
+    s = emu_solver(workers=4, slice_conflicts=10)
+    s.add_cnf(cnf.lits, cnf.offsets)
+    s.sweep_begin([[-int(cnf.card_outputs[k])] for k in ks])
+    s.sweep_drop([1])
+    s.sweep_step()                                                             # the workers of bound 2 move to bound 3
+    s.sweep_reopen([1])
+    res = None
+    for _ in range(400):
+        res, _ = s.sweep_step()
+        if all(r != SolverResult.Interrupted for r in res):
+            break
+    s.sweep_end()
+    assert [r.name for r in res] == ["Unsat", "Unsat"]
+    s.close()
+
+
 @pytest.mark.parametrize("one_per_simd", [2, 4], ids=["two-waves-build", "full-fleet-build"])
 def test_emulated_called_builds_of_the_search_kernel(one_per_simd):
     """The search kernel exists in three builds (waves per SIMD 1 / 2 / 4).  Small fleets run the inlined one; this forces
@@ -561,3 +585,20 @@ def test_emulated_called_builds_of_the_search_kernel(one_per_simd):
         if want == "Sat":
             check_sat_answer(cnf, s.full_solution(cnf.n_vars), enc, grid, k)
         s.close()
+
+
+def test_emulated_deterministic_mode_repeats_itself():
+    """opts.deterministic: conflict-bounded slices, ordered collection of the exchanged clauses, no ramp-up, nobody leaves a
+    slice early - two runs with the same seed report the same counters (and the golden verdict)."""
+    grid = make_grid("rect8x8")
+    enc = Encoding.encode(platform_defs("1x1"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 3}))
+    runs = []
+    for _ in range(2):
+        s = Mi355Sat(_lib_override=emu_lib(), workers=4, slice_conflicts=25, deterministic=1, seed=7, simp=-1)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        assert s.solve() == SolverResult.Unsat
+        st = s.stats()
+        runs.append((st["conflicts"], st["propagations"], st["decisions"], st["shared_exported"], st["shared_imported"]))
+        s.close()
+    assert runs[0] == runs[1] and runs[0][0] > 0 and runs[0][3] > 0

@@ -508,3 +508,22 @@ def test_large_terrains_with_1x1_supports_only(terrain, k):
         if not c:
             assert n == tl[i] and np.array_equal(v, vals[i])
     s.close()
+
+
+def test_deterministic_mode_repeats_itself_on_the_gpu():
+    """opts.deterministic = 1 (include/mi355sat.h): conflict-bounded slices, ordered clause collection, the whole fleet from
+    the first slice, no early exits - two runs of the rect 24x24 k = 8 refutation (golden: UNSAT) with the default fleet
+    and the exchange on report identical counters.  The default mode does not (slices are time-bounded)."""
+    grid = make_grid("rect24x24")
+    enc = Encoding.encode(platform_defs("default"), grid)
+    cnf = enc.with_limits_into_cnf(PlatformLimits({(1, 1): 8}))
+    runs = []
+    for _ in range(2):
+        s = Mi355Sat(deterministic=1, seed=11)
+        s.add_cnf(cnf.lits, cnf.offsets)
+        assert solve_within(s, HARD_RUNG_LIMIT_S) == SolverResult.Unsat
+        st = s.stats()
+        runs.append((st["conflicts"], st["propagations"], st["decisions"], st["restarts"], st["shared_exported"], st["shared_imported"]))
+        s.close()
+    assert runs[0] == runs[1], runs
+    assert runs[0][0] > 0 and runs[0][4] > 0

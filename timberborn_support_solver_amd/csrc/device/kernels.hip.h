@@ -106,7 +106,6 @@ struct Wk {
     LdsU32 lzero;  // (LV) variables assigned at level 0
     LdsU32 lfail;  // (LV) recursive minimisation: variables the learnt clause does not imply (all zero between analyses)
     LdsU32 lq;     // (LV) ... variables already in the node list
-    LdsI32 mnodes; // (LV) ... the node list: every variable visited outside the clause
     LdsU32 mcnt;   // (LV) ... its length
     LdsI32 bfl;     // the false literal of each lane group of the current BCP step
     // hot uniform scalars
@@ -822,7 +821,7 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
 
 // ---- recursive clause minimisation (LDS builds) -------------------------------------------------------
 // A literal of the learnt clause is redundant if every other literal of its reason is in the clause, fixed at level 0,
-// or itself implied by the clause in this sense (MiniSat's litRedundant).  Wave form: a node list in LDS takes every
+// or itself implied by the clause in this sense (MiniSat's litRedundant).  Wave form: a node list (in the slab) takes every
 // variable outside the clause that a reason leads to (each once: bitmap `lq`); the list is expanded 64 nodes at a time,
 // breadth first - a node whose reason's other variables are all marked (clause / level 0 / proven) is marked in `lseen`
 // like a clause literal, a decision, a variable of a level the clause does not touch (MiniSat's abstract levels) or one
@@ -835,12 +834,17 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
 #define MS_DEEP_MIN 1      // 0: local minimisation only (A/B)
 #endif
 #ifndef MS_MIN_NODES
-#define MS_MIN_NODES 512
+#define MS_MIN_NODES 4096   // (the list lives in the slab, in the array the clause-database reduction uses for its renumbering)
 #endif
+#ifndef MS_MIN_REASON
 #define MS_MIN_REASON 32
+#endif
+#ifndef MS_MIN_PASSES
 #define MS_MIN_PASSES 6
+#endif
 // state of variable y given its record: 0 = every other variable of its reason is marked, 1 = some are still open,
 // 2 = cannot be implied.  `queue`: open children join the node list.
+DEV uint32_t min_nodes_cap(const MsLayout& L) { return L.learnt_cap < MS_MIN_NODES ? L.learnt_cap : MS_MIN_NODES; }
 DEV int min_scan(Wk& w, const MsShared& sh, const MsLayout& L, int y, const MsVarRec& vr, bool queue, int size_cap) {
     const int r = vr.reason;
     int st = 0;
@@ -853,7 +857,7 @@ DEV int min_scan(Wk& w, const MsShared& sh, const MsLayout& L, int y, const MsVa
         if (queue && !(w.lq[c >> 5] & bit)) {
             if (!(lds_or_rtn(&w.lq[c >> 5], bit) & bit)) {          // the lane that flips the bit appends the node
                 const uint32_t k = lds_add(w.mcnt, 1u);
-                if (k < MS_MIN_NODES) w.mnodes[k] = c;
+                if (k < min_nodes_cap(L)) WKA(int32_t, remap)[k] = c;
                 else lds_and(&w.lq[c >> 5], ~bit);                  // list full: the child stays open for ever
             }
         }
@@ -880,6 +884,7 @@ DEV int min_scan(Wk& w, const MsShared& sh, const MsLayout& L, int y, const MsVa
     return st;
 }
 DEV void deep_minimize_marks(Wk& w, const MsShared& sh, const MsLayout& L, Gp<const int32_t> learnt_buf, int n_out) {
+    Gp<const int32_t> nodes = WKA(int32_t, remap);
     if (w.lane == 0) *w.mcnt = 0;
     lds_fence();
     // seeds: the open children of the clause literals' (short) reasons; the levels the clause touches
@@ -899,11 +904,11 @@ DEV void deep_minimize_marks(Wk& w, const MsShared& sh, const MsLayout& L, Gp<co
     // expansion, breadth first
     int head = 0;
     for (;;) {
-        const int n = min((int)uni((int)*w.mcnt), MS_MIN_NODES);
+        const int n = min((int)uni((int)*w.mcnt), (int)min_nodes_cap(L));
         if (head >= n) break;
         const int idx = head + w.lane;
         if (idx < n) {
-            const int z = w.mnodes[idx];
+            const int z = nodes[idx];
             const MsVarRec zr = VREC[z];
             const bool dead = zr.reason == MS_REASON_NONE || !((abs_levels >> (zr.level & 31)) & 1u);
             const int st = dead ? 2 : min_scan(w, sh, L, z, zr, true, MS_MIN_REASON);
@@ -914,14 +919,14 @@ DEV void deep_minimize_marks(Wk& w, const MsShared& sh, const MsLayout& L, Gp<co
         lds_fence();
     }
     // settle the nodes that waited for their children: youngest first, until a pass changes nothing
-    const int n = min((int)uni((int)*w.mcnt), MS_MIN_NODES);
+    const int n = min((int)uni((int)*w.mcnt), (int)min_nodes_cap(L));
     for (int pass = 0; pass < MS_MIN_PASSES; pass++) {
         bool changed = false;
         for (int i0 = ((n - 1) / MS_WAVE) * MS_WAVE; i0 >= 0; i0 -= MS_WAVE) {
             const int idx = i0 + w.lane;
             bool ch = false;
             if (idx < n) {
-                const int z = w.mnodes[idx];
+                const int z = nodes[idx];
                 const uint32_t bit = 1u << (z & 31);
                 if (!((w.lseen[z >> 5] | w.lfail[z >> 5]) & bit)) {
                     const int st = min_scan(w, sh, L, z, VREC[z], false, MS_MIN_REASON);
@@ -936,10 +941,11 @@ DEV void deep_minimize_marks(Wk& w, const MsShared& sh, const MsLayout& L, Gp<co
     }
 }
 // the marks of the node list go again (clause literals are not in it; theirs are cleared with the analysis marks)
-DEV void deep_minimize_clear(Wk& w) {
-    const int n = min((int)uni((int)*w.mcnt), MS_MIN_NODES);
+DEV void deep_minimize_clear(Wk& w, const MsLayout& L) {
+    Gp<const int32_t> nodes = WKA(int32_t, remap);
+    const int n = min((int)uni((int)*w.mcnt), (int)min_nodes_cap(L));
     for (int idx = w.lane; idx < n; idx += MS_WAVE) {
-        const int z = w.mnodes[idx];
+        const int z = nodes[idx];
         const uint32_t m = ~(1u << (z & 31));
         lds_and(&w.lseen[z >> 5], m); lds_and(&w.lfail[z >> 5], m); lds_and(&w.lq[z >> 5], m);
     }
@@ -1175,7 +1181,7 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
         wave_fence();
     }
     n_out = j;
-    if (LV && MS_DEEP_MIN) deep_minimize_clear(w);
+    if (LV && MS_DEEP_MIN) deep_minimize_clear(w, L);
     // ---- backjump level = max level among learnt_buf[1..), moved to position 1
     int bt = 0;
     if (n_out > 1) {
@@ -1562,7 +1568,8 @@ DEV void proof_log_deletions(Wk& w, const MsLayout& L, LoopState* pls, bool dl, 
         if (w.lane >= o) incl += t;
     }
     const uint32_t total = (uint32_t)bcast((int)incl, 63), base = (uint32_t)uni((int)*pls->proof_len);
-    if (base + total <= pls->proof_cap && dl) {
+    if (base + total > pls->proof_cap) return;      // no room: deletion lines are optional (a lost LEMMA fails the solve)
+    if (dl) {
         Gp<int32_t> out = pls->proof_buf + base + (incl - need);
         Gp<const int32_t> lits = WK_PTR(int32_t, w, L, lc_lits) + o0;
         out[0] = -2;
@@ -1937,7 +1944,6 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     __shared__ uint32_t s_lbdq[64];
     __shared__ int32_t s_bfl[MS_MAX_GROUPS];
     __shared__ uint32_t s_ov;
-    __shared__ int32_t s_mnodes[MS_MIN_NODES];
     __shared__ uint32_t s_mcnt;
     HIP_DYNAMIC_SHARED(uint32_t, s_lval)
     const uint32_t wid = blockIdx.x;
@@ -1950,7 +1956,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
     w.lfail = w.lzero + ((sh.n_vars + 31) >> 5);
     w.lq = w.lfail + ((sh.n_vars + 31) >> 5);
-    w.mnodes = (LdsI32)s_mnodes; w.mcnt = (LdsU32)&s_mcnt;
+    w.mcnt = (LdsU32)&s_mcnt;
     if (w.lane == 0) { s_ov = 0; s_mcnt = 0; }
     if (LV) for (uint32_t i = (uint32_t)w.lane; i < ((sh.n_vars + 31) >> 5); i += MS_WAVE) { w.lseen[i] = 0; w.lfail[i] = 0; w.lq[i] = 0; }
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
@@ -2085,7 +2091,6 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     __shared__ uint32_t s_hist[64];
     __shared__ int32_t s_bfl[MS_MAX_GROUPS];
     __shared__ uint32_t s_ov;
-    __shared__ int32_t s_mnodes[MS_MIN_NODES];
     __shared__ uint32_t s_mcnt;
     HIP_DYNAMIC_SHARED(uint32_t, s_lval)
     const uint32_t wid = blockIdx.x;
@@ -2098,7 +2103,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
     w.lfail = w.lzero + ((sh.n_vars + 31) >> 5);
     w.lq = w.lfail + ((sh.n_vars + 31) >> 5);
-    w.mnodes = (LdsI32)s_mnodes; w.mcnt = (LdsU32)&s_mcnt;
+    w.mcnt = (LdsU32)&s_mcnt;
     if (w.lane == 0) { s_ov = 0; s_mcnt = 0; }
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     wk_uniformize(w);
@@ -2140,7 +2145,6 @@ __global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout
     __shared__ uint32_t s_hist[64];
     __shared__ int32_t s_bfl[MS_MAX_GROUPS];
     __shared__ uint32_t s_ov;
-    __shared__ int32_t s_mnodes[MS_MIN_NODES];
     __shared__ uint32_t s_mcnt;
     HIP_DYNAMIC_SHARED(uint32_t, s_lval)
     const uint32_t wid = blockIdx.x;
@@ -2153,7 +2157,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout
     w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
     w.lfail = w.lzero + ((sh.n_vars + 31) >> 5);
     w.lq = w.lfail + ((sh.n_vars + 31) >> 5);
-    w.mnodes = (LdsI32)s_mnodes; w.mcnt = (LdsU32)&s_mcnt;
+    w.mcnt = (LdsU32)&s_mcnt;
     if (w.lane == 0) { s_ov = 0; s_mcnt = 0; }
     wk_bind<LV>(w, sh, L, slabs + (size_t)wid * L.slab_bytes, prm);
     wk_uniformize(w);

@@ -150,13 +150,18 @@ __device__ inline unsigned long long share_mix(unsigned long long x) {
 }
 __global__ void ms_share_collect_kernel(MsLayout L, char* slabs, uint32_t n_workers, int32_t* pool, uint32_t slots,
                                         unsigned long long* share_n, unsigned long long* hash, uint32_t hash_mask,
-                                        uint32_t* intake, uint32_t intake_cap) {
-    const uint32_t wid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (wid >= n_workers) return;
+                                        uint32_t* intake, uint32_t intake_cap, int ordered) {
+    // ordered (opts.deterministic): ONE thread takes the workers in index order, so ring order, the hash set's races and the
+    // intake cut-off do not depend on timing
+    uint32_t wid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ordered) {
+        if (wid != 0) return;
+    } else if (wid >= n_workers) return;
+  for (; wid < n_workers; wid++) {
     char* slab = slabs + (size_t)wid * L.slab_bytes;
     MsState* st = (MsState*)(slab + L.state);
     const uint32_t n = st->exp_n;
-    if (!n) return;
+    if (!n) { if (ordered) continue; return; }
     const int32_t* exp = (const int32_t*)(slab + L.exp);
     for (uint32_t r = 0; r < n && r < MS_EXPORT_RECS; r++) {
         const int32_t* rec = exp + r * MS_SHARE_REC;
@@ -182,6 +187,8 @@ __global__ void ms_share_collect_kernel(MsLayout L, char* slabs, uint32_t n_work
         for (int j = 0; j <= sz; j++) dst[j] = rec[j];
     }
     st->exp_n = 0;
+    if (!ordered) return;
+  }
 }
 
 // Subsumption and self-subsuming resolution (the other half of what `simp::Glucose` does before search; its
@@ -230,7 +237,7 @@ __global__ void ms_subsume_kernel(uint32_t n_clauses, const int32_t* lits, const
             if (dz < sz) continue;
             const int r = subsume_check(lits, offs, c, d);
             if (r == 1) { if (dz > sz || c < d) subsumed[d] = 1; }          // equal clauses: the lower index stays
-            else if (r >= 2) atomicCAS((int*)&drop_lit[d], -1, r - 2);      // one literal per clause and pass
+            else if (r >= 2) atomicMax((int*)&drop_lit[d], r - 2);          // one literal per clause and pass (the largest: the choice does not depend on timing)
         }
     }
 }
@@ -1379,13 +1386,14 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     if (active == 0 || active > s.n_alloc) active = s.n_alloc;   // workers [0, active) run this slice
     MsParams prm{};
     prm.n_workers = active;
-    prm.slice_conflicts = s.opts.slice_conflicts > 0 ? (uint32_t)s.opts.slice_conflicts : 0xffffffffu;
+    const bool deterministic = s.opts.deterministic > 0;
+    prm.slice_conflicts = s.opts.slice_conflicts > 0 ? (uint32_t)s.opts.slice_conflicts : (deterministic ? 200u : 0xffffffffu);
     prm.slice_props = 0;
     // default: time-bounded slices (all workers stop together; no straggler tail), 20 ms
-    const int slice_ms = s.opts.slice_ms > 0 ? s.opts.slice_ms : (s.opts.slice_conflicts > 0 ? 0 : auto_slice_ms);
+    const int slice_ms = deterministic ? 0 : (s.opts.slice_ms > 0 ? s.opts.slice_ms : (s.opts.slice_conflicts > 0 ? 0 : auto_slice_ms));
     prm.slice_ticks = slice_ms > 0 ? (uint64_t)slice_ms * 100000ull : 0;
     prm.stop_flag = s.stop_flag;
-    prm.stop_on_any = stop_on_any ? 1 : 0;
+    prm.stop_on_any = stop_on_any && !deterministic ? 1 : 0;
     prm.max_groups = s.opts.max_groups > 0 ? s.opts.max_groups : MS_MAX_GROUPS;
     prm.any_done = s.d_any_done.p;
     prm.done_on_refuted = done_on_refuted ? 1 : 0;
@@ -1449,9 +1457,10 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
         if ((++s.share_slices & 255) == 0)   // forget old signatures before the set fills up (a clause may then be passed on twice)
             HIPCHK(hipMemsetAsync(s.d_share_hash.p, 0, sizeof(unsigned long long) * s.share_hash_n, s.stream));
         HIPCHK(hipMemsetAsync(s.d_share_intake.p, 0, sizeof(uint32_t), s.stream));
-        hipLaunchKernelGGL(ms_share_collect_kernel, dim3((s.n_alloc + 63) / 64), dim3(64), 0, s.stream, s.L, s.d_slabs.p,
+        const bool ordered = s.opts.deterministic > 0;
+        hipLaunchKernelGGL(ms_share_collect_kernel, dim3(ordered ? 1 : (s.n_alloc + 63) / 64), dim3(ordered ? 1 : 64), 0, s.stream, s.L, s.d_slabs.p,
                            s.n_alloc, s.d_share_pool.p, s.share_slots, s.d_share_n.p, s.d_share_hash.p, s.share_hash_n - 1,
-                           s.d_share_intake.p, share_intake_cap);
+                           s.d_share_intake.p, share_intake_cap, ordered ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventSynchronize(s.ev1));
@@ -1606,13 +1615,15 @@ int sweep_begin(mi355sat& s, Sweep& sw, const std::vector<int32_t>& assump, cons
     for (uint32_t i = 0; i < n_instances; i++)
         max_assumps = std::max<uint32_t>(max_assumps, (uint32_t)(assump_off[i + 1] - assump_off[i]));
     const uint32_t assump_cap = sw.split ? max_assumps + 512 : max_assumps;
-    const uint32_t initial = (s.opts.ramp >= 0 && !sw.split) ? std::max(256u, n_instances) / n_instances * n_instances : 0;
+    const uint32_t initial = (s.opts.ramp >= 0 && !sw.split && s.opts.deterministic <= 0) ? std::max(256u, n_instances) / n_instances * n_instances : 0;
     upload_formula(s, P, assump_cap, 0, want, initial);
     if (s.n_workers < n_instances) throw HipErr{"not enough device memory for one worker per instance"};
     s.n_workers = s.n_workers / n_instances * n_instances;
     s.n_alloc = std::min(s.n_alloc, s.n_workers);
-    if (!s.proof_path.empty()) {   // one log per worker, drained after every slice (4 MiB each: ~10^4 learnt clauses per slice)
-        s.proof_cap = 1u << 20;
+    if (!s.proof_path.empty()) {   // one log per worker, drained after every slice: a slice's lemmas (~10^4 learnt clauses) plus the
+        // deletion lines of one clause-database reduction, which may drop half of a full learnt store at once (lemmas that do
+        // not fit fail the solve - the proof would be wrong; deletion lines that do not fit are dropped - they are optional)
+        s.proof_cap = (uint32_t)std::min<uint64_t>(1u << 23, (1u << 20) + s.L.learnt_lit_cap / 2 + 2ull * s.L.learnt_cap);
         s.d_proof.alloc((size_t)s.n_workers * s.proof_cap);
         s.d_proof_len.alloc(s.n_workers);
         HIPCHK(hipMemsetAsync(s.d_proof_len.p, 0, sizeof(uint32_t) * s.n_workers, s.stream));
@@ -1750,6 +1761,16 @@ void rebalance_workers(mi355sat& s, Sweep& sw) {
                 movable.push_back(w);
             }
         }
+        // an open instance nobody works on (reopened with every worker busy elsewhere, or its workers' slabs came later)
+        // takes one worker from the instance that has the most - weights or not: it would never be decided otherwise
+        for (uint32_t i : open) {
+            if (cnt[i] > 0 || !movable.empty()) continue;
+            uint32_t rich = open[0];
+            for (uint32_t j : open) if (cnt[j] > cnt[rich]) rich = j;
+            if (cnt[rich] <= 1) break;
+            for (uint32_t w = s.n_alloc; w-- > 0;)
+                if ((uint32_t)sw.w_inst[w] == rich && sw.sts[w].status == MS_ST_RUNNING) { movable.push_back(w); cnt[rich]--; break; }
+        }
         for (uint32_t w : movable) {
             uint32_t best = open[0];
             double best_need = -1e30;
@@ -1786,11 +1807,19 @@ int sweep_step(mi355sat& s, Sweep& sw) {
     // 32x32 k=120 0.167 -> 0.088 s; 250 / 1000 ms thresholds gain nothing more at 64x64 - a worker there is bound
     // by DRAM latency even when alone - and delay the rect 24x24 ladder by 0.5-1 s.)
     uint32_t active = s.n_workers;
-    if (s.opts.ramp >= 0 && !sw.split) {
+    if (s.opts.ramp >= 0 && !sw.split && s.opts.deterministic <= 0) {
         const uint32_t want = sw.ramp_ms < 100.f ? 256u : (sw.ramp_ms < 400.f ? 1024u : s.n_workers);
         active = std::min(s.n_workers, std::max(want, n_instances) / n_instances * n_instances);
     }
-    if (active > s.n_alloc) grow_workers(s, n_instances, active);
+    if (active > s.n_alloc) {
+        const uint32_t had = s.n_alloc;
+        grow_workers(s, n_instances, active);
+        // the new workers start on instance w % n_instances - which may be decided or withdrawn by now: move them before the slice
+        if (n_instances > 1 && !sw.split && s.n_alloc > had && !sw.sts.empty() && (sw.decided > 0 || std::count(sw.dropped.begin(), sw.dropped.end(), 1) > 0)) {
+            sw.sts.resize(s.n_workers, MsState{});
+            rebalance_workers(s, sw);
+        }
+    }
     // default slice length: 20 ms while a solve is young (easy bounds are decided within a few), 50 ms after one second
     // and 100 ms after ten of kernel time - the host's share per slice (collecting states, the caller's loop) was a
     // quarter of the wall-clock of the rect 26x26 ladder with 10 ms slices
@@ -2029,7 +2058,7 @@ int mi355sat_solve(mi355sat* s) {
         std::vector<uint64_t> aoff{0, 0};
         std::vector<int32_t> results, winner;
         int rc = run_search(*s, assump, aoff, 1, results, winner, true);
-        if (rc) { s->stats.solve_seconds += now_s() - t0; return rc; }
+        if (rc) { proof_close(*s, false); s->stats.solve_seconds += now_s() - t0; return rc; }   // (a truncated proof file is closed, not leaked)
         result = results[0];
         proof_close(*s, result == MI355SAT_UNSAT);
         s->model.clear();

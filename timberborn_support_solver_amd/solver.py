@@ -39,7 +39,7 @@ class Mi355SatOpts(ctypes.Structure):
                 ("slice_conflicts", ctypes.c_int32), ("seed", ctypes.c_uint64), ("verbose", ctypes.c_int32),
                 ("reduce_first", ctypes.c_int32), ("reduce_inc", ctypes.c_int32), ("lds_val", ctypes.c_int32),
                 ("max_groups", ctypes.c_int32), ("slice_ms", ctypes.c_int32), ("cube_split", ctypes.c_int32), ("share", ctypes.c_int32), ("share_lbd", ctypes.c_int32), ("share_len", ctypes.c_int32),
-                ("share_interval", ctypes.c_int32), ("var_order", ctypes.c_int32), ("ramp", ctypes.c_int32), ("one_per_simd", ctypes.c_int32), ("simp", ctypes.c_int32), ("phase_mix", ctypes.c_int32), ("rephase", ctypes.c_int32), ("restart_k_pct", ctypes.c_int32), ("restart_k2_pct", ctypes.c_int32), ("import_pct", ctypes.c_int32), ("vivify", ctypes.c_int32), ("rebalance", ctypes.c_int32)]
+                ("share_interval", ctypes.c_int32), ("var_order", ctypes.c_int32), ("ramp", ctypes.c_int32), ("one_per_simd", ctypes.c_int32), ("simp", ctypes.c_int32), ("phase_mix", ctypes.c_int32), ("rephase", ctypes.c_int32), ("restart_k_pct", ctypes.c_int32), ("restart_k2_pct", ctypes.c_int32), ("import_pct", ctypes.c_int32), ("vivify", ctypes.c_int32), ("rebalance", ctypes.c_int32), ("deterministic", ctypes.c_int32)]
 
 
 class Mi355SatStats(ctypes.Structure):
@@ -126,7 +126,7 @@ class Interrupter:
 
 class Mi355Sat:
     def __init__(self, device=-1, workers=0, conflict_budget=0, slice_conflicts=0, seed=0, verbose=0,
-                 reduce_first=0, reduce_inc=0, lds_val=0, max_groups=0, slice_ms=0, cube_split=0, share=0, share_lbd=0, share_len=0, share_interval=0, rebalance=0, var_order=0, ramp=0, one_per_simd=0, simp=0, phase_mix=0, rephase=0, restart_k_pct=0, restart_k2_pct=0, import_pct=0, vivify=0, _lib_override=None):
+                 reduce_first=0, reduce_inc=0, lds_val=0, max_groups=0, slice_ms=0, cube_split=0, share=0, share_lbd=0, share_len=0, share_interval=0, rebalance=0, var_order=0, ramp=0, one_per_simd=0, simp=0, phase_mix=0, rephase=0, restart_k_pct=0, restart_k2_pct=0, import_pct=0, vivify=0, deterministic=0, _lib_override=None):
         # _lib_override: test hook (the wavefront-emulator build under tests/emu); the product
         # always binds the HIP library and fails loudly without it.
         raw = _lib_override if _lib_override is not None else _lib.solver_lib()
@@ -135,7 +135,7 @@ class Mi355Sat:
         self._L = _bound[id(raw)]
         opts = Mi355SatOpts(device=device, workers=workers, conflict_budget=conflict_budget,
                             slice_conflicts=slice_conflicts, seed=seed, verbose=verbose,
-                            reduce_first=reduce_first, reduce_inc=reduce_inc, lds_val=lds_val, max_groups=max_groups, slice_ms=slice_ms, cube_split=cube_split, share=share, share_lbd=share_lbd, share_len=share_len, share_interval=share_interval, rebalance=rebalance, var_order=var_order, ramp=ramp, one_per_simd=one_per_simd, simp=simp, phase_mix=phase_mix, rephase=rephase, restart_k_pct=restart_k_pct, restart_k2_pct=restart_k2_pct, import_pct=import_pct, vivify=vivify)
+                            reduce_first=reduce_first, reduce_inc=reduce_inc, lds_val=lds_val, max_groups=max_groups, slice_ms=slice_ms, cube_split=cube_split, share=share, share_lbd=share_lbd, share_len=share_len, share_interval=share_interval, rebalance=rebalance, var_order=var_order, ramp=ramp, one_per_simd=one_per_simd, simp=simp, phase_mix=phase_mix, rephase=rephase, restart_k_pct=restart_k_pct, restart_k2_pct=restart_k2_pct, import_pct=import_pct, vivify=vivify, deterministic=deterministic)
         self._h = self._L.mi355sat_new(ctypes.byref(opts))
         if not self._h:
             raise SolverError("mi355sat_new failed: " + (self._L.mi355sat_last_error(None) or b"").decode())
