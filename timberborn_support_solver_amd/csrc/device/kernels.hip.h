@@ -57,7 +57,9 @@ typedef unsigned long long u64;
 #define PROF_MARK(slot)
 #define PROF_RESET
 #endif
-enum { PF_OFF = 0, PF_BIN, PF_TERN, PF_LONG, PF_CLOSE, PF_ANALYZE, PF_BACKJUMP, PF_DECIDE, PF_REDUCE, PF_N };
+enum { PF_OFF = 0, PF_BIN, PF_TERN, PF_LONG, PF_CLOSE, PF_ANALYZE, PF_BACKJUMP, PF_DECIDE, PF_REDUCE, PF_N,
+       // counts and sub-phases of conflict analysis (slots behind the phase shares)
+       PF_RES_STEPS = PF_N, PF_MIN_DEEP, PF_MIN_LOCAL, PF_MIN_NODES, PF_MIN_CALLS, PF_ALL };
 
 #define DEV __device__ __forceinline__
 // cold paths are real calls: keeps them out of the hot loop's register allocation
@@ -122,7 +124,7 @@ struct Wk {
     uint32_t c_props, c_watch, c_move, c_enq, c_dec, c_steps, c_redo;
     uint32_t c_cl_lit;  // per lane
 #ifdef MS_PROFILE
-    u64 prof[PF_N + 1];        // phase cycles + [PF_N] = resolution steps of conflict analysis
+    u64 prof[PF_ALL];          // phase cycles, then counts / sub-phases of conflict analysis
 #endif
 };
 
@@ -1135,7 +1137,14 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     // assignment the clause's own literals (and level 0) imply get marked like clause literals - then the local test
     // below is the recursive one.  Measured on the CPU restatement (rect 26x26 k = 10): 4.2e5 conflicts and learnt
     // clauses of 36 literals with it, 8.0e5 and 177 with the local test alone.
+#ifdef MS_PROFILE
+    u64 tmin_ = __builtin_readcyclecounter();
+#endif
     if (LV && MS_DEEP_MIN && n_out > 2) deep_minimize_marks(w, sh, L, learnt_buf, n_out);
+#ifdef MS_PROFILE
+    if (LV && MS_DEEP_MIN && n_out > 2) { w.prof[PF_MIN_NODES] += (u64)uni((int)*w.mcnt); w.prof[PF_MIN_CALLS]++; }
+    { const u64 t_ = __builtin_readcyclecounter(); w.prof[PF_MIN_DEEP] += t_ - tmin_; tmin_ = t_; }
+#endif
     // ---- local minimisation: drop a literal whose reason's other literals are all seen / level 0.
     // One learnt literal per lane; a long reason is read four literals per load (clauses start 16-byte aligned)
     // and a literal's level is only fetched when it is not marked.
@@ -1182,6 +1191,9 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     }
     n_out = j;
     if (LV && MS_DEEP_MIN) deep_minimize_clear(w, L);
+#ifdef MS_PROFILE
+    w.prof[PF_MIN_LOCAL] += __builtin_readcyclecounter() - tmin_;
+#endif
     // ---- backjump level = max level among learnt_buf[1..), moved to position 1
     int bt = 0;
     if (n_out > 1) {
@@ -1495,7 +1507,7 @@ DEV void wk_bind(Wk& w, const MsShared& sh, const MsLayout& L, char* slab, const
     w.confl_kind = 0; w.confl_cref = 0; w.confl_a = 0; w.confl_b = 0; w.confl_c = 0;
     w.c_props = w.c_watch = w.c_move = w.c_enq = w.c_dec = w.c_steps = w.c_redo = 0; w.c_cl_lit = 0;
 #ifdef MS_PROFILE
-    for (int i = 0; i <= PF_N; i++) w.prof[i] = 0;
+    for (int i = 0; i < PF_ALL; i++) w.prof[i] = 0;
 #endif
     if (LV) {  // stage the assignment in LDS for this slice: 16 bytes of the slab -> one word of 2-bit fields
         Gp<const uint4> gv = (Gp<const uint4>)WKA(uint8_t, val);
@@ -1525,7 +1537,7 @@ DEV void wk_store(Wk& w, const MsShared& sh, const MsLayout& L, u64 cycles) {
         s->slice_cycles += cycles;
         s->n_steps += w.c_steps; s->n_redo += w.c_redo;
 #ifdef MS_PROFILE
-        for (int i = 0; i <= PF_N; i++) s->prof[i] += w.prof[i];
+        for (int i = 0; i < PF_ALL; i++) s->prof[i] += w.prof[i];
 #endif
     }
 }

@@ -154,7 +154,7 @@ struct MsState {
     uint64_t slice_cycles;
     uint64_t n_steps;          // BCP steps (each propagates up to MS_MAX_GROUPS literals)
     uint64_t n_redo;           // literals re-queued because two groups met in one clause
-    uint64_t prof[10];         // per-phase cycle totals (profiling build only)
+    uint64_t prof[16];         // per-phase cycle totals and counts (profiling build only)
     // clause exchange
     uint64_t share_pos;        // records of the global ring this worker has looked at
     uint64_t n_exported, n_imported, n_imported_units;

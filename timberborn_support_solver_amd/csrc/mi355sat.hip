@@ -1349,16 +1349,19 @@ void accumulate_stats(mi355sat& s, const std::vector<MsState>& sts) {
     uint64_t exported = 0, imported = 0, imported_units = 0;
     for (auto& st : sts) { exported += st.n_exported; imported += st.n_imported; imported_units += st.n_imported_units; }
     o.shared_exported += exported; o.shared_imported += imported; o.shared_imported_units += imported_units;
-    uint64_t prof[10] = {0}, cyc = 0;
-    for (auto& st : sts) { for (int i = 0; i < 10; i++) prof[i] += st.prof[i]; cyc += st.slice_cycles; }
+    uint64_t prof[16] = {0}, cyc = 0;
+    for (auto& st : sts) { for (int i = 0; i < 16; i++) prof[i] += st.prof[i]; cyc += st.slice_cycles; }
     if (prof[0] && s.opts.verbose) {
         static const char* nm[] = {"offsets", "binary", "ternary", "long", "close", "analyze", "backjump+learn", "decide", "reduce"};
         fprintf(stderr, "[mi355sat] phase cycle shares of %.3e worker-cycles:", (double)cyc);
         for (int i = 0; i < 9; i++) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)prof[i] / (double)cyc);
         uint64_t confl = 0, ll = 0, lt = 0;
         for (auto& st : sts) { confl += st.conflicts; ll += st.learnt_lits_total; lt += st.learnt_total; }
-        fprintf(stderr, "; resolution steps per conflict %.1f, learnt clause %.1f literals\n", (double)prof[9] / (double)std::max<uint64_t>(1, confl),
+        fprintf(stderr, "; resolution steps per conflict %.1f, learnt clause %.1f literals", (double)prof[9] / (double)std::max<uint64_t>(1, confl),
                 (double)ll / (double)std::max<uint64_t>(1, lt));
+        fprintf(stderr, "; of analyze: recursive minimisation %.1f%%, local %.1f%%; %.1f nodes per call, %.2f calls per conflict\n",
+                100.0 * (double)prof[10] / (double)cyc, 100.0 * (double)prof[11] / (double)cyc,
+                (double)prof[12] / (double)std::max<uint64_t>(1, prof[13]), (double)prof[13] / (double)std::max<uint64_t>(1, confl));
     }
 }
 
