@@ -16,13 +16,15 @@ cpu_limit = float(sys.argv[4]) if len(sys.argv) > 4 else 240
 for m in sizes:
     g = WorldGrid.rect(m, m)
     e = Encoding.encode(PLATFORMS_DEFAULT, g)
-    k, tc, kstar, confl = m, time.perf_counter(), None, 0
+    k, tc, kstar, confl, cpu_rungs = m, time.perf_counter(), None, 0, []
     while time.perf_counter() - tc < cpu_limit:
         ck = e.with_limits_into_cnf(PlatformLimits({(1, 1): k}))
         o = ora.OracleSolver()
         o.add_cnf(ck.lits, ck.offsets)
+        tr = time.perf_counter()
         r = o.solve(conflict_budget=20_000_000)
         confl += o.stats()["conflicts"]
+        cpu_rungs.append((k, {10: "Sat", 20: "Unsat"}.get(r, "Interrupted"), round(time.perf_counter() - tr, 1)))
         if r == 20:
             kstar = k + 1
             break
@@ -30,13 +32,13 @@ for m in sizes:
             break
         k = PlatformLayout.from_assignment(o.model(ck.n_vars)[:e.n_vars], e).platform_count() - 1
     cpu_s = time.perf_counter() - tc
-    print(f"rect {m}: CPU done in {cpu_s:.1f} s", flush=True)   # (keeps a long rung from looking hung)
+    print(f"rect {m}: CPU done in {cpu_s:.1f} s: {cpu_rungs}", flush=True)   # (keeps a long rung from looking hung)
     gpu = []
     for rep in range(reps):
         t0 = time.perf_counter()
         hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=limit, make_solver=lambda: Mi355Sat())
         ok = hist[-1]["result"] == SolverResult.Unsat
         gpu.append((round(time.perf_counter() - t0, 2), [h["count"] for h in hist if h["count"]][-1] if ok else None,
-                    [round(h["seconds"], 1) for h in hist[-2:]]))
+                    [(h["k"], h["result"].name, h["count"], round(h["seconds"], 1)) for h in hist]))
         print(f"rect {m}: GPU run {rep} {gpu[-1]}", flush=True)
     print(f"rect {m} -l1:{m}: CPU {cpu_s:.2f} s (k*={kstar}, {confl} conflicts) | GPU batch loop {gpu}", flush=True)
