@@ -958,15 +958,18 @@ DEV void deep_minimize_clear(Wk& w, const MsLayout& L) {
 // ---- conflict analysis (first UIP) -----------------------------------------
 struct Learnt { int n, bt_level; uint32_t lbd; };
 
-template <bool LV>
-DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, MsVarRec* vrec, int32_t* toclear, int32_t* learnt_buf, bool act, int q, int dl,
+// CLAIM: the lanes may hold literals of DIFFERENT clauses (batched resolution), so two of them may present the same
+// variable: the mark is set with a fetch-or and only the lane that flipped the bit counts it.
+template <bool LV, bool CLAIM = false>
+DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, Gp<MsVarRec> vrec, Gp<int32_t> toclear, Gp<int32_t> learnt_buf, bool act, int q, int dl,
                        int& path_c, int& n_out, int& n_clear) {
     int v = q >> 1;
     bool fresh = false, cur = false;
     if (LV) {   // everything analysis asks about a literal is a bit in LDS: marked? level 0? current level?
         if (act) {
             const uint32_t bit = 1u << (v & 31);
-            fresh = !(w.lseen[v >> 5] & bit) && !(w.lzero[v >> 5] & bit);
+            if (CLAIM) fresh = !(w.lzero[v >> 5] & bit) && !(w.lseen[v >> 5] & bit) && !(lds_or_rtn(&w.lseen[v >> 5], bit) & bit);
+            else fresh = !(w.lseen[v >> 5] & bit) && !(w.lzero[v >> 5] & bit);
             cur = fresh && (w.lcur[v >> 5] & bit);
         }
     } else if (act) {
@@ -977,13 +980,120 @@ DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, MsVarRec* v
     u64 fm = ballot(fresh), cm = ballot(cur);
     u64 lm = fm & ~cm;
     if (fresh) {
-        seen_set<LV>(w, sh, L, v);
+        if (!(LV && CLAIM)) seen_set<LV>(w, sh, L, v);
         toclear[n_clear + popc64(fm & lanemask_lt(w.lane))] = v;
         if (!cur) learnt_buf[n_out + popc64(lm & lanemask_lt(w.lane))] = q;
     }
     n_clear += popc64(fm);
     n_out += popc64(lm);
     path_c += popc64(cm);
+}
+
+// One long clause, 64 literals per round (wave-cooperative).
+template <bool LV>
+DEV void analyze_visit_clause(Wk& w, const MsShared& sh, const MsLayout& L, Gp<MsVarRec> vrec, Gp<int32_t> toclear, Gp<int32_t> learnt_buf,
+                              Gp<const int32_t> cl, int size, int skip_var, int dl, int& path_c, int& n_out, int& n_clear) {
+    for (int k0 = 0; k0 < size; k0 += MS_WAVE) {
+        const int k = k0 + w.lane;
+        const int q = k < size ? cl[k] : 0;
+        analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, k < size && (q >> 1) != skip_var, q, dl, path_c, n_out, n_clear);
+    }
+}
+
+// (LDS builds) The backward walk of first-UIP analysis over the trail, 64 entries at a time (one coalesced load, lane
+// i holds position chunk_hi - i; the marks are bits in LDS, so the whole chunk is tested at once).  BATCHED: as long
+// as more marked literals of the current level are open than this chunk holds (path_c > marked-in-chunk), none of the
+// chunk's marked literals can be the first UIP - at least one open literal lies further down the trail - so ALL of them
+// are resolved in one round: every lane marks the literals of its own literal's reason (records and reason heads of all
+// of them fetched together; binary, ternary and short long reasons are then in registers).  The marks are a set union,
+// so the order of the resolutions does not matter; reasons point backwards on the trail, so what a round newly marks
+// inside the chunk is picked up by the next round.  Once the chunk holds every open literal, the walk is sequential
+// (the last open one is the UIP and must not be resolved).  Round 2 resolved one literal per iteration (~160 per
+// conflict at ~1 us each).  Returns the UIP literal, or -1 (internal error).
+template <bool LV>
+DEV int analyze_walk_lds(Wk& w, const MsShared& sh, const MsLayout& L, Gp<MsVarRec> vrec, Gp<int32_t> toclear, Gp<int32_t> learnt_buf,
+                         Gp<uint32_t> lc_lbd, int dl, int& path_c, int& n_out, int& n_clear) {
+    int index = w.trail_n - 1;
+    for (;;) {
+        if (index < 0) { w.status = MS_ST_ERR_INTERNAL; return -1; }
+        const int chunk_hi = index;
+        const int pos = chunk_hi - w.lane;
+        const int my = pos >= 0 ? WKA(int32_t, trail)[pos] : 0;
+        const int myv = my >> 1;
+        bool have = false;          // this lane's record and reason head are in registers
+        MsVarRec rec = MsVarRec{0, MS_REASON_NONE, 0, 0, 0, 0};
+        int4 l0 = make_int4(0, 0, 0, 0), l1 = make_int4(0, 0, 0, 0);
+        for (;;) {
+            lds_fence();
+            const bool mine = pos >= 0 && pos <= index && ((w.lseen[myv >> 5] >> (myv & 31)) & 1u);
+            const u64 sm = ballot(mine);
+            if (sm == 0) break;
+            const int cnt = popc64(sm);
+            if (mine && !have) {    // records, then reason heads, of every marked literal of the chunk not fetched yet
+                rec = vrec[myv];
+                const int rr = rec.reason;
+                if (rr >= 0 && rec.size > 0) {
+                    Gp<const int32_t> cl = lits_base(w, sh, L, rr) + rec.start;
+                    l0 = *(Gp<const int4>)cl;
+                    if (rec.size > 4) l1 = *(Gp<const int4>)(cl + 4);
+                } else if (rr < 0 && MS_IS_TERN_REASON(rr)) {
+                    const int e = MS_TERN_REASON_ENTRY(rr);
+                    const int2 tp = ((Gp<const int2>)sh.tern_pairs)[e];
+                    l0 = make_int4(((Gp<const int32_t>)sh.tern_owner)[e] ^ 1, tp.x, tp.y, 0);
+                }
+                have = true;
+            }
+            const bool batch = path_c > cnt;
+            const int f = first_lane(sm);
+            const bool me = batch ? mine : w.lane == f;      // the lanes whose literal is resolved in this round
+#ifdef MS_PROFILE
+            w.prof[PF_RES_STEPS] += (u64)(batch ? cnt : 1);
+#endif
+            if (batch) path_c -= cnt;
+            else {
+                index = chunk_hi - f - 1;
+                path_c--;
+                if (path_c <= 0) {      // the first UIP: not resolved
+                    if (me) lds_and(&w.lseen[myv >> 5], ~(1u << (myv & 31)));
+                    lds_fence();
+                    return bcast(my, f);
+                }
+            }
+            // the reasons: up to 8 literals per lane from registers, longer clauses afterwards one at a time
+            const int r = rec.reason;
+            int nl = 0;
+            bool big = false;
+            if (me) {
+                if (r >= 0) { if (rec.size > 0 && rec.size <= 8) nl = (int)rec.size; else big = true; }
+                else if (MS_IS_TERN_REASON(r)) nl = 3;
+                else if (MS_IS_BIN_REASON(r)) { nl = 1; l0.x = MS_BIN_REASON_LIT(r); }
+                else { big = false; nl = -1; }      // a marked decision above the UIP cannot be
+                if (r >= 0 && (uint32_t)r >= sh.n_orig) lc_lbd[(uint32_t)r - sh.n_orig] |= 0x80000000u;   // used
+            }
+            if (ballot(me && nl < 0)) { w.status = MS_ST_ERR_INTERNAL; return -1; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int q = j < 4 ? (j == 0 ? l0.x : (j == 1 ? l0.y : (j == 2 ? l0.z : l0.w)))
+                                    : (j == 4 ? l1.x : (j == 5 ? l1.y : (j == 6 ? l1.z : l1.w)));
+                const bool act = me && j < nl && (q >> 1) != myv;
+                if (ballot(me && j < nl) == 0) break;
+                analyze_visit<LV, true>(w, sh, L, vrec, toclear, learnt_buf, act, q, dl, path_c, n_out, n_clear);
+            }
+            for (u64 bm = ballot(me && big); bm != 0; bm &= bm - 1) {
+                const int fb = first_lane(bm);
+                const int cref = bcast(r, fb);
+                Gp<const int32_t> cl;
+                int size = bcast((int)rec.size, fb);
+                if (size > 0) cl = lits_base(w, sh, L, cref) + (uint32_t)bcast((int)rec.start, fb);
+                else clause_range(w, sh, L, cref, cl, size);
+                analyze_visit_clause<LV>(w, sh, L, vrec, toclear, learnt_buf, cl, size, bcast(myv, fb), dl, path_c, n_out, n_clear);
+            }
+            // the resolved literals' own marks go LAST: while they stand, no reason of this round can mark them anew
+            lds_fence();
+            if (me) lds_and(&w.lseen[myv >> 5], ~(1u << (myv & 31)));
+        }
+        index = chunk_hi - MS_WAVE;     // nothing marked is left in this chunk at or below `index`
+    }
 }
 
 template <bool LV>
@@ -1005,6 +1115,21 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     int pre_n = 0;
     const int dl = w.n_levels;
     int kind = w.confl_kind, cref = w.confl_cref, ba = w.confl_a, bb = w.confl_b, bc = w.confl_c;
+    if (LV) {       // the conflict clause, then the batched walk (analyze_walk_lds)
+        if (kind == 1) {
+            Gp<const int32_t> cl;
+            int size = bc;
+            if (size > 0) cl = lits_base(w, sh, L, cref) + (uint32_t)bb;
+            else clause_range(w, sh, L, cref, cl, size);
+            if ((uint32_t)cref >= sh.n_orig && w.lane == 0) lc_lbd[cref - sh.n_orig] |= 0x80000000u;  // used
+            analyze_visit_clause<LV>(w, sh, L, vrec, toclear, learnt_buf, cl, size, -1, dl, path_c, n_out, n_clear);
+        } else {
+            const int q = w.lane == 0 ? ba : (w.lane == 1 ? bb : bc);
+            analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, w.lane < kind, q, dl, path_c, n_out, n_clear);
+        }
+        p = analyze_walk_lds<LV>(w, sh, L, vrec, toclear, learnt_buf, lc_lbd, dl, path_c, n_out, n_clear);
+        if (p < 0) return Learnt{0, 0, 0};
+    } else
     for (;;) {
         if (kind == 1) {
             Gp<const int32_t> cl;
