@@ -846,7 +846,7 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
 #endif
 // state of variable y given its record: 0 = every other variable of its reason is marked, 1 = some are still open,
 // 2 = cannot be implied.  `queue`: open children join the node list.
-DEV uint32_t min_nodes_cap(const MsLayout& L) { return L.learnt_cap < MS_MIN_NODES ? L.learnt_cap : MS_MIN_NODES; }
+DEV uint32_t min_nodes_cap(const MsLayout& L) { return L.learnt_cap / 2 < MS_MIN_NODES ? L.learnt_cap / 2 : MS_MIN_NODES; }   // (node list + waiting list share the array)
 DEV int min_scan(Wk& w, const MsShared& sh, const MsLayout& L, int y, const MsVarRec& vr, bool queue, int size_cap) {
     const int r = vr.reason;
     int st = 0;
@@ -903,32 +903,37 @@ DEV void deep_minimize_marks(Wk& w, const MsShared& sh, const MsLayout& L, Gp<co
     }
     for (int o = 32; o > 0; o >>= 1) abs_levels |= (uint32_t)__shfl_xor((int)abs_levels, o, 64);
     lds_fence();
-    // expansion, breadth first
-    int head = 0;
+    // expansion, breadth first; the nodes that have to wait for a child go to a second list
+    Gp<int32_t> waiting = WKA(int32_t, remap) + min_nodes_cap(L);
+    int head = 0, n_wait = 0;
     for (;;) {
         const int n = min((int)uni((int)*w.mcnt), (int)min_nodes_cap(L));
         if (head >= n) break;
         const int idx = head + w.lane;
+        int z = 0, st = 0;
         if (idx < n) {
-            const int z = nodes[idx];
+            z = nodes[idx];
             const MsVarRec zr = VREC[z];
             const bool dead = zr.reason == MS_REASON_NONE || !((abs_levels >> (zr.level & 31)) & 1u);
-            const int st = dead ? 2 : min_scan(w, sh, L, z, zr, true, MS_MIN_REASON);
+            st = dead ? 2 : min_scan(w, sh, L, z, zr, true, MS_MIN_REASON);
             if (st == 0) lds_or(&w.lseen[z >> 5], 1u << (z & 31));
             else if (st == 2) lds_or(&w.lfail[z >> 5], 1u << (z & 31));
         }
+        const u64 wm = ballot(idx < n && st == 1);
+        if (idx < n && st == 1) waiting[n_wait + popc64(wm & lanemask_lt(w.lane))] = z;
+        n_wait += popc64(wm);
         head = min(head + MS_WAVE, n);
         lds_fence();
     }
     // settle the nodes that waited for their children: youngest first, until a pass changes nothing
-    const int n = min((int)uni((int)*w.mcnt), (int)min_nodes_cap(L));
-    for (int pass = 0; pass < MS_MIN_PASSES; pass++) {
+    const int n = n_wait;
+    for (int pass = 0; pass < MS_MIN_PASSES && n > 0; pass++) {
         bool changed = false;
         for (int i0 = ((n - 1) / MS_WAVE) * MS_WAVE; i0 >= 0; i0 -= MS_WAVE) {
             const int idx = i0 + w.lane;
             bool ch = false;
             if (idx < n) {
-                const int z = nodes[idx];
+                const int z = waiting[idx];
                 const uint32_t bit = 1u << (z & 31);
                 if (!((w.lseen[z >> 5] | w.lfail[z >> 5]) & bit)) {
                     const int st = min_scan(w, sh, L, z, VREC[z], false, MS_MIN_REASON);
