@@ -374,7 +374,11 @@ struct LongRes {
 // watched pair, loaded by the caller together with everything else the step needs.  All values are a
 // snapshot taken before the step's commit.  Must be called by all 64 lanes (phase B is wave-cooperative).
 template <bool LV>
-DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, bool live, int vbl, int2 ww, int fl, int g) {
+// (LV) h0 / h1: the clause's first 8 literals, loaded by the caller together with the watched pair - the blocker's value is
+// known at once there, so pair and literals are ONE round trip; with the assignment in the slab they are loaded here, only
+// for the watchers whose blocker turned out not to be true.
+DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, bool live, int vbl, int2 ww, int fl, int g,
+                      int4 h0 = make_int4(0, 0, 0, 0), int4 h1 = make_int4(0, 0, 0, 0)) {
     const MsClauseHdr ch = MsClauseHdr{(uint32_t)wt.z, (uint32_t)wt.w};
     LongRes R;
     R.wt = wt; R.live = live; R.keep = live; R.want = false; R.cf = false; R.deferred = false; R.imp = 0;
@@ -389,7 +393,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
         int ls[MS_LANE_SCAN], vs[MS_LANE_SCAN];
 #pragma unroll
         for (int k = 0; k < MS_LANE_SCAN; k += 4) {
-            const int4 q = k < size ? gld<int4>((Gp<const int4>)(cl + k)) : make_int4(fl, fl, fl, fl);
+            const int4 q = k < size ? (LV ? (k == 0 ? h0 : h1) : gld<int4>((Gp<const int4>)(cl + k))) : make_int4(fl, fl, fl, fl);
             ls[k] = q.x; ls[k + 1] = q.y; ls[k + 2] = q.z; ls[k + 3] = q.w;
         }
         vo = lit_value<LV>(w, sh, L, other);
@@ -542,6 +546,12 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int vc = act_t ? lit_value<LV>(w, sh, L, pr0.y) : MS_VAL_TRUE;
         const int vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
         const int2 ww0 = (live0 && (!LV || vbl0 != MS_VAL_TRUE)) ? gld<int2>((Gp<const int2>)&wl[wt0.x]) : make_int2(0, 0);
+        int4 h00 = make_int4(0, 0, 0, 0), h01 = make_int4(0, 0, 0, 0);
+        if (LV && live0 && vbl0 != MS_VAL_TRUE) {
+            Gp<const int32_t> cl0 = lits_base(w, sh, L, wt0.x) + (uint32_t)wt0.z;
+            h00 = *(Gp<const int4>)cl0;
+            if (wt0.w > 4) h01 = *(Gp<const int4>)(cl0 + 4);
+        }
         PROF_MARK(PF_OFF);
         // evaluate binary + ternary entries on the snapshot
         const bool cf_b = vq == MS_VAL_FALSE, want_b = vq == MS_VAL_UNDEF;
@@ -553,7 +563,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         PROF_MARK(PF_BIN);
         // first chunk of the watch lists (round trips 3..: other watch + clause literals, pushes)
         int j = 0, done = 0, defer_g = MS_MAX_GROUPS;
-        LongRes R0 = long_eval<LV>(w, sh, L, wt0, live0, vbl0, ww0, fl, g);
+        LongRes R0 = long_eval<LV>(w, sh, L, wt0, live0, vbl0, ww0, fl, g, h00, h01);
         PROF_MARK(PF_LONG);
         // ONE commit for the whole first chunk: binary, ternary and watched-clause implications
         bool any_cf;
@@ -666,8 +676,14 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 const bool live = act && wt.x >= 0;
                 const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
                 const int2 ww = (live && (!LV || vbl != MS_VAL_TRUE)) ? gld<int2>((Gp<const int2>)&wl[wt.x]) : make_int2(0, 0);
+                int4 h0 = make_int4(0, 0, 0, 0), h1 = make_int4(0, 0, 0, 0);
+                if (LV && live && vbl != MS_VAL_TRUE) {
+                    Gp<const int32_t> clh = lits_base(w, sh, L, wt.x) + (uint32_t)wt.z;
+                    h0 = *(Gp<const int4>)clh;
+                    if (wt.w > 4) h1 = *(Gp<const int4>)(clh + 4);
+                }
                 w.c_watch += (uint32_t)popc64(ballot(live));
-                LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, fl_l, gl);
+                LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, fl_l, gl, h0, h1);
                 w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
                 const u64 km = ballot(R.keep);
                 wave_fence();
@@ -830,8 +846,9 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
 // with a failed child goes to `lfail`; the rest waits for its children and is settled by a few passes over the list,
 // youngest nodes first (reasons point backwards on the trail, so there are no cycles).  What is not settled by then
 // counts as not implied: the result is a clause between the locally and the fully minimised one, always a consequence
-// of the formula by the same resolution steps.  Bounded: MS_MIN_NODES nodes, reasons of at most MS_MIN_REASON literals
-// for nodes (a longer one fails the node; clause literals themselves are tested against reasons of any length).
+// of the formula by the same resolution steps.  Bounded: MS_MIN_NODES nodes; a clause literal hands its reason's open
+// variables to the list if that reason has at most MS_MIN_REASON literals (it is TESTED against reasons of any length), an
+// inner node needs a reason of at most 8 (min_scan8).
 #ifndef MS_DEEP_MIN
 #define MS_DEEP_MIN 1      // 0: local minimisation only (A/B)
 #endif
@@ -885,6 +902,51 @@ DEV int min_scan(Wk& w, const MsShared& sh, const MsLayout& L, int y, const MsVa
     else return 2;      // a decision
     return st;
 }
+// The same for a NODE: only reasons of at most 8 literals (binary, ternary, short clauses - on the CPU restatement a cap of
+// 8 / 16 / 24 literals on inner nodes costs nothing: the chains run through the totalizer's and the overlap families'
+// short clauses), both halves loaded at once: one round trip per node instead of one per four literals.
+DEV int min_scan8(Wk& w, const MsShared& sh, const MsLayout& L, int y, const MsVarRec& vr, bool queue) {
+    const int r = vr.reason;
+    int4 a = make_int4(0, 0, 0, 0), b = make_int4(0, 0, 0, 0);
+    int n = 0;
+    if (r >= 0) {
+        if (vr.size == 0 || vr.size > 8) return 2;
+        Gp<const int32_t> cl = lits_base(w, sh, L, r) + vr.start;
+        a = *(Gp<const int4>)cl;
+        if (vr.size > 4) b = *(Gp<const int4>)(cl + 4);
+        n = (int)vr.size;
+    } else if (MS_IS_TERN_REASON(r)) {
+        const int e = MS_TERN_REASON_ENTRY(r);
+        const int2 pr = ((Gp<const int2>)sh.tern_pairs)[e];
+        a = make_int4(((Gp<const int32_t>)sh.tern_owner)[e] ^ 1, pr.x, pr.y, 0);
+        n = 3;
+    } else if (MS_IS_BIN_REASON(r)) { a.x = MS_BIN_REASON_LIT(r); n = 1; }
+    else return 2;
+    int st = 0;
+    auto child = [&](int l) {
+        const int c = l >> 1;
+        const uint32_t bit = 1u << (c & 31);
+        if (c == y || ((w.lseen[c >> 5] | w.lzero[c >> 5]) & bit)) return;
+        if (w.lfail[c >> 5] & bit) { st = 2; return; }
+        if (st < 1) st = 1;
+        if (queue && !(w.lq[c >> 5] & bit)) {
+            if (!(lds_or_rtn(&w.lq[c >> 5], bit) & bit)) {
+                const uint32_t k = lds_add(w.mcnt, 1u);
+                if (k < min_nodes_cap(L)) WKA(int32_t, remap)[k] = c;
+                else lds_and(&w.lq[c >> 5], ~bit);
+            }
+        }
+    };
+    child(a.x);
+    if (n > 1) child(a.y);
+    if (n > 2) child(a.z);
+    if (n > 3) child(a.w);
+    if (n > 4) child(b.x);
+    if (n > 5) child(b.y);
+    if (n > 6) child(b.z);
+    if (n > 7) child(b.w);
+    return st;
+}
 DEV void deep_minimize_marks(Wk& w, const MsShared& sh, const MsLayout& L, Gp<const int32_t> learnt_buf, int n_out) {
     Gp<const int32_t> nodes = WKA(int32_t, remap);
     if (w.lane == 0) *w.mcnt = 0;
@@ -915,7 +977,7 @@ DEV void deep_minimize_marks(Wk& w, const MsShared& sh, const MsLayout& L, Gp<co
             z = nodes[idx];
             const MsVarRec zr = VREC[z];
             const bool dead = zr.reason == MS_REASON_NONE || !((abs_levels >> (zr.level & 31)) & 1u);
-            st = dead ? 2 : min_scan(w, sh, L, z, zr, true, MS_MIN_REASON);
+            st = dead ? 2 : min_scan8(w, sh, L, z, zr, true);
             if (st == 0) lds_or(&w.lseen[z >> 5], 1u << (z & 31));
             else if (st == 2) lds_or(&w.lfail[z >> 5], 1u << (z & 31));
         }
@@ -936,7 +998,7 @@ DEV void deep_minimize_marks(Wk& w, const MsShared& sh, const MsLayout& L, Gp<co
                 const int z = waiting[idx];
                 const uint32_t bit = 1u << (z & 31);
                 if (!((w.lseen[z >> 5] | w.lfail[z >> 5]) & bit)) {
-                    const int st = min_scan(w, sh, L, z, VREC[z], false, MS_MIN_REASON);
+                    const int st = min_scan8(w, sh, L, z, VREC[z], false);
                     if (st == 0) { lds_or(&w.lseen[z >> 5], bit); ch = true; }
                     else if (st == 2) { lds_or(&w.lfail[z >> 5], bit); ch = true; }
                 }
