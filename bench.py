@@ -270,6 +270,33 @@ def main():
     solver.sweep_end()
     solver.close()
 
+    # The same sweep in the PRODUCT'S default configuration (learnt-clause exchange on): not `value` - with the exchange
+    # on, what a worker does in slice n depends on what was collected after slice n - 1, i.e. on slice timing - but
+    # reported beside it so that the headline is not mistaken for the default configuration.
+    exchange_window = None
+    if rank == 0 and world == 1 and args.share < 0 and not args.no_cpu:
+        s2 = Mi355Sat(device=device_index, workers=workers, slice_ms=args.slice_ms, seed=1000, _lib_override=lib_override,
+                      var_order=args.var_order, share=0, ramp=-1)
+        s2.add_cnf(cnf.lits, cnf.offsets)
+        s2.reserve(cnf.n_vars)
+        s2.sweep_begin(assumption_sets)
+        for _ in range(min(3, args.warmup)):
+            s2.sweep_step()
+        a0, ta = s2.stats(), time.perf_counter()
+        n2 = max(1, min(8, args.steps))
+        for _ in range(n2):
+            s2.sweep_step()
+        torch.cuda.synchronize()
+        dta = time.perf_counter() - ta
+        a1 = s2.stats()
+        exchange_window = {"slices": n2, "propagations_per_s": (a1["propagations"] - a0["propagations"]) / dta,
+                           "conflicts_per_s": (a1["conflicts"] - a0["conflicts"]) / dta,
+                           "clauses_attached_from_the_exchange": int(a1["shared_imported"] - a0["shared_imported"]),
+                           "note": "product default (exchange on), same workload and fleet; not the headline value"}
+        s2.sweep_end()
+        s2.close()
+        note(f"exchange on: {exchange_window['propagations_per_s']:.3e} propagations/s, {exchange_window['conflicts_per_s']:.3e} conflicts/s")
+
     # ---- wall-clock to first UNSAT on the largest rung that finishes in bench time (64x64 does not:
     # SURVEY §6).  GPU: the product's own loop, solver_loop_sweep (first bound alone as the reference makes it,
     # then every lower bound as one batch until max UNSAT k + 1 == min count).  CPU: the reference's
@@ -386,6 +413,7 @@ def main():
                         "per_step": per_step,
                        "note": "rank 0's rate in consecutive thirds of the timed region; per_step: the rate of every slice"},
             "conflicts_per_s": total_confl / max_dt,
+            "exchange_on_window": exchange_window,
             "decided_instances": int(decided),
             "first_unsat_wall_clock_s": first_unsat[-1]["gpu_seconds"] if first_unsat else None,
             "first_unsat": first_unsat,

@@ -134,6 +134,7 @@ struct Wk {
 #define WKA(T, field) ((Gp<T>)(w.slab + L.field))
 #define VREC WKA(MsVarRec, vrec)
 #define VMPOS WKA(int32_t, vm_pos)
+#define HX(t) MS_HIDX(t, L.n_vars)      // slot of literal t's header in whdr
 
 DEV u64 ballot(bool p) { return __ballot(p); }
 DEV int popc64(u64 m) { return __popcll(m); }
@@ -327,10 +328,10 @@ DEV MsClauseHdr clause_hdr_of(const Wk& w, const MsShared& sh, const MsLayout& L
 DEV bool list_push_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int t, int cref, int blocker, uint32_t start, uint32_t size) {
     Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
     Gp<int4> pool = WKA(int4, pool);
-    uint32_t s = (uint32_t)uni((int)whdr[t].size);
-    uint32_t cap = (uint32_t)uni((int)whdr[t].cap);
+    uint32_t s = (uint32_t)uni((int)whdr[HX(t)].size);
+    uint32_t cap = (uint32_t)uni((int)whdr[HX(t)].cap);
     if (s > cap) s = cap;  // overshoot left by failed atomic pushes
-    uint32_t base = (uint32_t)uni((int)whdr[t].base);
+    uint32_t base = (uint32_t)uni((int)whdr[HX(t)].base);
     if (s == cap) {
         uint32_t ncap = cap < 4 ? 8 : cap * 2;
         if (w.pool_top + ncap > L.pool_cap) { w.status = MS_ST_ERR_POOL; return false; }
@@ -338,10 +339,10 @@ DEV bool list_push_uniform(Wk& w, const MsShared& sh, const MsLayout& L, int t, 
         w.pool_top += ncap;
         for (uint32_t i = (uint32_t)w.lane; i < s; i += MS_WAVE) pool[nb + i] = pool[base + i];
         wave_fence();
-        if (w.lane == 0) { whdr[t].base = nb; whdr[t].cap = ncap; }
+        if (w.lane == 0) { whdr[HX(t)].base = nb; whdr[HX(t)].cap = ncap; }
         base = nb;
     }
-    if (w.lane == 0) { pool[base + s] = make_int4(cref, blocker, (int)start, (int)size); whdr[t].size = s + 1; }
+    if (w.lane == 0) { pool[base + s] = make_int4(cref, blocker, (int)start, (int)size); whdr[HX(t)].size = s + 1; }
     wave_fence();
     return true;
 }
@@ -442,7 +443,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
     const bool push = scanning && r >= 0;
     const int t = r ^ 1;
     Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
-    const int4 th = push ? gld<int4>((Gp<const int4>)&whdr[t]) : make_int4(0, 0, 0, 0);   // {base, size, cap, -}
+    const int4 th = push ? gld<int4>((Gp<const int4>)&whdr[HX(t)]) : make_int4(0, 0, 0, 0);   // {base, size, cap, -}
     int rank = 0, cnt = 0;
     for (u64 pm = ballot(push); pm != 0;) {
         const int tf = bcast(t, first_lane(pm));
@@ -463,7 +464,7 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
                 ov[3 * o + 1] = wt.x;
                 ov[3 * o + 2] = other;
             }
-            if (rank == 0) whdr[t].size = tsize + (uint32_t)cnt;
+            if (rank == 0) whdr[HX(t)].size = tsize + (uint32_t)cnt;
             R.keep = false;
         } else if (vo == MS_VAL_FALSE) R.cf = true;
         else { R.want = true; R.imp = other; }
@@ -521,7 +522,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int qbase = w.qhead;
         const int idx = qbase + g;
         const int p = (idx >= w.ring_lo) ? w.ring[idx & (MS_LDS_RING - 1)] : trail[idx];
-        const MsWatchHdr wh = whdr[p];   // watch list + binary / ternary list headers: one line
+        const MsWatchHdr wh = whdr[HX(p)];   // watch list + binary / ternary list headers: one line
         const int fl = p ^ 1;
         const uint32_t b0 = wh.bin_off, nb = wh.bin_n, t0 = wh.tern_off, nt = wh.tern_n;
         const uint32_t wb = wh.base;
@@ -711,7 +712,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         // between the compacted prefix and the first unvisited entry
         wave_fence();
         if (done == n) {
-            if (sl == 0 && n > 0 && j != n) whdr[p].size = (uint32_t)j;
+            if (sl == 0 && n > 0 && j != n) whdr[HX(p)].size = (uint32_t)j;
         } else {
             for (int x = j + sl; x < done; x += S) pool[wb + x] = make_int4(-1, 0, 0, 0);
         }
@@ -1464,8 +1465,8 @@ DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
     wave_fence();
     for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
         const int2 ww = make_int2(wl[c].w0, wl[c].w1);
-        atomicAdd(&whdr[ww.x ^ 1].size, 1u);
-        atomicAdd(&whdr[ww.y ^ 1].size, 1u);
+        atomicAdd(&whdr[HX(ww.x ^ 1)].size, 1u);
+        atomicAdd(&whdr[HX(ww.y ^ 1)].size, 1u);
     }
     wave_fence();
     uint32_t run = 0;
@@ -1487,10 +1488,10 @@ DEV void rebuild_watches(Wk& w, const MsShared& sh, const MsLayout& L) {
     wave_fence();
     for (uint32_t c = (uint32_t)w.lane; c < ncl; c += MS_WAVE) {
         const MsClauseRec cr = wl[c];
-        uint32_t pa = atomicAdd(&whdr[cr.w0 ^ 1].size, 1u);
-        pool[whdr[cr.w0 ^ 1].base + pa] = make_int4((int)c, cr.w1, (int)cr.start, (int)cr.size);
-        uint32_t pb = atomicAdd(&whdr[cr.w1 ^ 1].size, 1u);
-        pool[whdr[cr.w1 ^ 1].base + pb] = make_int4((int)c, cr.w0, (int)cr.start, (int)cr.size);
+        uint32_t pa = atomicAdd(&whdr[HX(cr.w0 ^ 1)].size, 1u);
+        pool[whdr[HX(cr.w0 ^ 1)].base + pa] = make_int4((int)c, cr.w1, (int)cr.start, (int)cr.size);
+        uint32_t pb = atomicAdd(&whdr[HX(cr.w1 ^ 1)].size, 1u);
+        pool[whdr[HX(cr.w1 ^ 1)].base + pb] = make_int4((int)c, cr.w0, (int)cr.start, (int)cr.size);
     }
     wave_fence();
 }

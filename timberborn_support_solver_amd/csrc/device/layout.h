@@ -73,6 +73,19 @@ struct MsLitHdr { uint32_t bin_off, bin_n, tern_off, tern_n; };
 // immutable binary / ternary list header, so that a dequeued literal costs ONE 32-byte access to one line
 // instead of a private and a shared one (+16 B x 2 x n_vars per worker: 3 MB of 37 at rect 64x64).
 struct MsWatchHdr { uint32_t base, size, cap, pad; uint32_t bin_off, bin_n, tern_off, tern_n; };
+// Where literal t's header is in `whdr`: polarity-major (all positive literals, then all negative ones), so that the
+// headers of CONSECUTIVE variables of one polarity are neighbours, two per 64-byte line.  A platform placed on the grid
+// falsifies the whole run of placement variables of every tile it covers at once (overlap clauses + the size chain): in
+// literal order (2v, 2v+1) each of those dequeued literals had a line of its own, half of it the header of the opposite
+// polarity that is not touched then.
+#ifndef MS_HDR_POLARITY_MAJOR
+#define MS_HDR_POLARITY_MAJOR 1
+#endif
+#if MS_HDR_POLARITY_MAJOR
+#define MS_HIDX(t, nv) ((((uint32_t)(t)) & 1u) * (uint32_t)(nv) + (((uint32_t)(t)) >> 1))
+#else
+#define MS_HIDX(t, nv) ((uint32_t)(t))
+#endif
 // Per-variable record: everything backtracking and analysis need to know about an assigned variable sits in ONE
 // 16-byte slot, written by ONE store when the variable is assigned: its level, its reason and - for a long / learnt
 // reason - where that clause's literals are (start, size; size 0 = look the clause record up), so that conflict

@@ -747,12 +747,12 @@ void build_layout_and_template(mi355sat& s, const Prepared& P, uint32_t assump_c
     MsWatchHdr* whdr = (MsWatchHdr*)(T + L.whdr);
     int4* pool = (int4*)(T + L.pool);
     for (size_t t = 0; t < cap.size(); t++)
-        whdr[t] = MsWatchHdr{base[t], 0, cap[t], 0, P.lit_hdr[t].bin_off, P.lit_hdr[t].bin_n, P.lit_hdr[t].tern_off, P.lit_hdr[t].tern_n};
+        whdr[MS_HIDX(t, nv)] = MsWatchHdr{base[t], 0, cap[t], 0, P.lit_hdr[t].bin_off, P.lit_hdr[t].bin_n, P.lit_hdr[t].tern_off, P.lit_hdr[t].tern_n};
     for (uint32_t c = 0; c < no; c++) {
         int32_t a = P.cl_lits[P.cl_hdr[c].start], b = P.cl_lits[P.cl_hdr[c].start + 1];
         wl[c] = MsClauseRec{a, b, P.cl_hdr[c].start, P.cl_hdr[c].size};
-        pool[whdr[a ^ 1].base + whdr[a ^ 1].size++] = make_int4((int)c, b, (int)P.cl_hdr[c].start, (int)P.cl_hdr[c].size);
-        pool[whdr[b ^ 1].base + whdr[b ^ 1].size++] = make_int4((int)c, a, (int)P.cl_hdr[c].start, (int)P.cl_hdr[c].size);
+        pool[whdr[MS_HIDX(a ^ 1, nv)].base + whdr[MS_HIDX(a ^ 1, nv)].size++] = make_int4((int)c, b, (int)P.cl_hdr[c].start, (int)P.cl_hdr[c].size);
+        pool[whdr[MS_HIDX(b ^ 1, nv)].base + whdr[MS_HIDX(b ^ 1, nv)].size++] = make_int4((int)c, a, (int)P.cl_hdr[c].start, (int)P.cl_hdr[c].size);
     }
 }
 
