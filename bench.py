@@ -308,7 +308,7 @@ def main():
         # (min SAT count, max UNSAT k) and the best model are the only things exchanged; in the replica
         # tail (the last bounds, every rank the same bound) the ranks also pass on the clauses they learn
         from timberborn_support_solver_amd.sweep import solver_loop_sweep_sharded
-        m = fu_sizes[0]
+        m = 26 if 26 in fu_sizes else fu_sizes[0]     # a ladder whose last bound takes tens of seconds: the replica tail and the ring matter
         g2 = WorldGrid.rect(m, m)
         e2 = Encoding.encode(defs, g2)
         st_sh = {}
