@@ -109,6 +109,7 @@ struct Wk {
     LdsU32 lfail;  // (LV) recursive minimisation: variables the learnt clause does not imply (all zero between analyses)
     LdsU32 lq;     // (LV) ... variables already in the node list
     LdsU32 mcnt;   // (LV) ... its length
+    LdsU32 sortbuf = nullptr; int sort_n = 0;   // queue positions of the analysed variables (bump order); 0 entries in the builds without it
     LdsI32 bfl;     // the false literal of each lane group of the current BCP step
     // hot uniform scalars
     int lane;
@@ -859,6 +860,9 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
 #ifndef MS_MIN_REASON
 #define MS_MIN_REASON 32
 #endif
+#ifndef MS_SORT_N
+#define MS_SORT_N 2048      // analysed variables sorted by queue position before they are bumped (LDS words per wave)
+#endif
 #ifndef MS_MIN_PASSES
 #define MS_MIN_PASSES 6
 #endif
@@ -1431,17 +1435,47 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
         }
         w.lvl_stamp_ctr = nb;
     }
-    // ---- clear marks and bump the analysed variables to the front of the queue, in the order analysis met them
-    // (measured in round 1: reversed order 3-7e4 conflicts per worker on the rect 20/24 rungs instead of 1-2e4, only
-    // the learnt clause's variables 7-13e4, by previous queue position like this order)
+    // ---- clear marks and bump the analysed variables to the front of the queue.  In WHICH ORDER they go there decides how
+    // good the search is on the hard bounds: sorted by their previous queue position (CaDiCaL's order: the analysed
+    // variables keep their relative order) against the order analysis met them, on the CPU restatement with a
+    // move-to-front queue in place of its VSIDS heap: rect 26 k = 10 3.9e5 against 6.8e5 conflicts, rect 28 k = 11 5.4e5
+    // against 1.67e6 (VSIDS: 4.2e5 / 4.4e5).  Round 1 compared the two on rect 20 / 24 only and saw no difference.  So:
+    // positions to LDS, bitonic sort (wave-wide, 64 pairs per pass), re-read the variables in that order.  More than
+    // MS_SORT_N analysed variables (rare) or a build without the sort buffer: the order analysis met them.
     if (w.vm_end + n_clear > (int)L.vm_cap) vm_compact(w, sh, L);
     {
         Gp<int32_t> vm_order = WK_PTR(int32_t, w, L, vm_order);
-        for (int i = w.lane; i < n_clear; i += MS_WAVE) {
-            int v = toclear[i];
-            seen_clr<LV>(w, sh, L, v);
-            vm_order[w.vm_end + i] = v;
-            VMPOS[v] = w.vm_end + i;
+        if (w.sort_n >= 64 && n_clear > 1 && n_clear <= w.sort_n) {
+            int N = 64;
+            while (N < n_clear) N <<= 1;
+            for (int i = w.lane; i < N; i += MS_WAVE) {
+                uint32_t key = 0xffffffffu;
+                if (i < n_clear) { const int v = toclear[i]; seen_clr<LV>(w, sh, L, v); key = (uint32_t)VMPOS[v]; }
+                w.sortbuf[i] = key;
+            }
+            lds_fence();
+            for (int k = 2; k <= N; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = w.lane; t < N / 2; t += MS_WAVE) {
+                        const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a + j;      // (j is a power of two)
+                        const uint32_t x = w.sortbuf[a], y = w.sortbuf[b];
+                        const bool asc = (a & k) == 0;
+                        if ((x > y) == asc) { w.sortbuf[a] = y; w.sortbuf[b] = x; }
+                    }
+                    lds_fence();
+                }
+            for (int i = w.lane; i < n_clear; i += MS_WAVE) {
+                const int v = vm_order[w.sortbuf[i]];      // (live entry: vm_order[vm_pos[v]] == v)
+                vm_order[w.vm_end + i] = v;
+                VMPOS[v] = w.vm_end + i;
+            }
+        } else {
+            for (int i = w.lane; i < n_clear; i += MS_WAVE) {
+                int v = toclear[i];
+                seen_clr<LV>(w, sh, L, v);
+                vm_order[w.vm_end + i] = v;
+                VMPOS[v] = w.vm_end + i;
+            }
         }
         w.vm_end += n_clear;
     }
@@ -1659,7 +1693,7 @@ DEV unsigned long long uni64(unsigned long long v) {
 DEV void wk_uniformize(Wk& w) {
     w.slab = (Gp<char>)uni64((unsigned long long)w.slab);
     w.trail_n = uni(w.trail_n); w.qhead = uni(w.qhead); w.n_levels = uni(w.n_levels); w.ring_lo = uni(w.ring_lo);
-    w.vm_end = uni(w.vm_end); w.vm_search = uni(w.vm_search);
+    w.vm_end = uni(w.vm_end); w.vm_search = uni(w.vm_search); w.sort_n = uni(w.sort_n);
     w.n_learnts = (uint32_t)uni((int)w.n_learnts); w.lc_lits_n = (uint32_t)uni((int)w.lc_lits_n);
     w.pool_top = (uint32_t)uni((int)w.pool_top);
     w.status = uni(w.status); w.lvl_stamp_ctr = (uint32_t)uni((int)w.lvl_stamp_ctr); w.max_groups = uni(w.max_groups);
@@ -2150,11 +2184,13 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     __shared__ int32_t s_bfl[MS_MAX_GROUPS];
     __shared__ uint32_t s_ov;
     __shared__ uint32_t s_mcnt;
+    __shared__ uint32_t s_sort[WPS <= 2 ? MS_SORT_N : 1];   // (16 waves per CU have no room for it)
     HIP_DYNAMIC_SHARED(uint32_t, s_lval)
     const uint32_t wid = blockIdx.x;
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
+    w.sortbuf = (LdsU32)s_sort; w.sort_n = WPS <= 2 ? MS_SORT_N : 0;
     w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl;
     w.lseen = w.lval + ((sh.n_vars + 15) >> 4);   // (LV) three bitmaps behind the assignment words
     w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);

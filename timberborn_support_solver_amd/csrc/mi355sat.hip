@@ -1427,7 +1427,7 @@ SliceResult launch_slice(mi355sat& s, int mode, bool stop_on_any, bool done_on_r
     bool lds = s.lds_val;
     if (mode == 0 && s.opts.lds_val == 0) {
         const uint32_t per_cu = (active + 255) / 256;
-        lds = s.lds_val_bytes <= std::min<uint32_t>(64 * 1024, 150 * 1024 / per_cu - 6 * 1024);   // (a workgroup's static 5.2 KB aside)
+        lds = s.lds_val_bytes <= std::min<uint32_t>(64 * 1024, 150 * 1024 / per_cu - (per_cu <= 8 ? 14 : 6) * 1024);   // (a workgroup's static LDS aside: 5.2 KB, 13.2 KB in the builds with the sort buffer)
     }
     const uint32_t dyn = lds ? s.lds_val_bytes : 0;
     HIPCHK(hipEventRecord(s.ev0, s.stream));
