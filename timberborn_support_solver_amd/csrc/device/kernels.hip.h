@@ -860,6 +860,9 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
 #ifndef MS_MIN_REASON
 #define MS_MIN_REASON 32
 #endif
+#ifndef MS_BUMP_REASON_SIDE
+#define MS_BUMP_REASON_SIDE 1
+#endif
 #ifndef MS_SORT_N
 #define MS_SORT_N 2048      // analysed variables sorted by queue position before they are bumped (LDS words per wave)
 #endif
@@ -1434,6 +1437,57 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
             nb = 0;
         }
         w.lvl_stamp_ctr = nb;
+    }
+    // ---- reason side (LDS builds with the sorted bump): the other variables of the short reasons of the learnt clause's
+    // literals are bumped too (CaDiCaL's "bump reason side", one level deep).  On the CPU restatement with the sorted
+    // move-to-front queue: rect 26 k = 10 3.5e5 against 3.9e5 conflicts, rect 28 k = 11 4.1e5 against 5.4e5.
+    if (LV && MS_BUMP_REASON_SIDE && w.sort_n > 0) {
+        // (`lq`, all zero outside the recursive minimisation, says here what is in `toclear` already: the resolved
+        // literals' analysis marks are gone by now)
+        for (int i = w.lane; i < n_clear; i += MS_WAVE) { const int v = toclear[i]; lds_or(&w.lq[v >> 5], 1u << (v & 31)); }
+        lds_fence();
+        const int n_clear0 = n_clear;
+        for (int i0 = 1; i0 < n_out; i0 += MS_WAVE) {
+            const int i = i0 + w.lane;
+            int4 a = make_int4(0, 0, 0, 0), b = make_int4(0, 0, 0, 0);
+            int n = 0, qv = -1;
+            if (i < n_out) {
+                qv = learnt_buf[i] >> 1;
+                const MsVarRec vr = VREC[qv];
+                const int r = vr.reason;
+                if (r >= 0) {
+                    if (vr.size > 0 && vr.size <= 8) {
+                        Gp<const int32_t> cl = lits_base(w, sh, L, r) + vr.start;
+                        a = *(Gp<const int4>)cl;
+                        if (vr.size > 4) b = *(Gp<const int4>)(cl + 4);
+                        n = (int)vr.size;
+                    }
+                } else if (MS_IS_TERN_REASON(r)) {
+                    const int e = MS_TERN_REASON_ENTRY(r);
+                    const int2 pr = ((Gp<const int2>)sh.tern_pairs)[e];
+                    a = make_int4(((Gp<const int32_t>)sh.tern_owner)[e] ^ 1, pr.x, pr.y, 0);
+                    n = 3;
+                } else if (MS_IS_BIN_REASON(r)) { a.x = MS_BIN_REASON_LIT(r); n = 1; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (ballot(j < n) == 0) break;
+                const int c = (j < 4 ? (j == 0 ? a.x : (j == 1 ? a.y : (j == 2 ? a.z : a.w)))
+                                     : (j == 4 ? b.x : (j == 5 ? b.y : (j == 6 ? b.z : b.w)))) >> 1;
+                bool fresh = false;
+                if (j < n && c != qv) {
+                    const uint32_t bit = 1u << (c & 31);
+                    fresh = !((w.lq[c >> 5] | w.lzero[c >> 5]) & bit) && !(lds_or_rtn(&w.lq[c >> 5], bit) & bit);
+                }
+                const u64 fm = ballot(fresh);
+                if (fresh) toclear[n_clear + popc64(fm & lanemask_lt(w.lane))] = c;
+                n_clear += popc64(fm);
+            }
+        }
+        lds_fence();
+        for (int i = w.lane; i < n_clear; i += MS_WAVE) { const int v = toclear[i]; lds_and(&w.lq[v >> 5], ~(1u << (v & 31))); }
+        (void)n_clear0;
+        lds_fence();
     }
     // ---- clear marks and bump the analysed variables to the front of the queue.  In WHICH ORDER they go there decides how
     // good the search is on the hard bounds: sorted by their previous queue position (CaDiCaL's order: the analysed
