@@ -107,7 +107,9 @@ typedef struct mi355sat_opts {
                                   0 = default: off (measured on rect 28x28 k = 12, a hard satisfiable bound: 4.3-6.3 s without,
                                   5.4-7.5 s with), 1 = every worker, 2 = every second worker */
     int32_t restart_k_pct;     /* Glucose's restart factor K in percent (restart when the LBD average of the last 50 conflicts times
-                                  K exceeds the global average); 0 = 80 */
+                                  K exceeds the global average); 0 = 100 (round 3, with the sorted bump order: rect 28 k = 11 / rect 32
+                                  k = 14 with 1024 workers 11.2 / 15.7 s at 100, 11.2-12.9 / 16.4-17.6 s at 90, 14.3 / 21.7 s at 80,
+                                  20.0 / 34.5 s at 70, 11.7 / 17.8 s at 110; profiles/r03_m_knob_sweep*.log) */
     int32_t restart_k2_pct;    /* > 0: every second worker uses this K instead (a portfolio of restart policies); 0 = same K */
     int32_t import_pct;        /* share (percent) of the exchanged clauses of 3 and more literals each worker attaches (every worker
                                   another share; units and binaries always); 0 = default 50: a worker that attaches everything
@@ -117,8 +119,9 @@ typedef struct mi355sat_opts {
     int32_t vivify;            /* vivification of learnt clauses: at a restart, every 400 conflicts, up to this many recent learnt
                                   clauses of LBD <= 6 (at most 64 literals) are re-derived literal by literal under unit
                                   propagation and replaced by the shorter clause that implies them (a RUP lemma, exported like a
-                                  freshly learnt clause); 0 = default 4 (measured, 1024 workers: rect 26 k = 10 37-45 s vs 46-72 s
-                                  without, rect 28 k = 11 46-54 s vs 59-80 s; 8 and 16 per pass: slower again), -1 = off.  No effect in
+                                  freshly learnt clause); > 0 = that many per pass; 0 = default: off (round 2 measured a quarter less
+                                  time with 4 per pass; on top of round 3's recursive minimisation it is the other way round: rect 28
+                                  k = 11 / rect 32 k = 14 10.5 / 15.9 s without, 12.9 / 17.6 s with, profiles/r03_m_knob_sweep2.log).  No effect in
                                   launches of more than 2048 workers: the full-fleet build leaves the code out */
     int32_t rebalance;         /* batched solves: 0 = default (on): workers of decided / withdrawn instances move to the open
                                   ones; -1 = they park */

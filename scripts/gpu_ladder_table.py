@@ -1,5 +1,6 @@
 """Wall-clock of the refinement loop `-l1:M` on rect M x M: the product's batch loop on the GPU (3 runs) against
 the CPU restatement's sequential loop on the GPU box's host (1 core).  GPU box only."""
+import os
 import sys
 import time
 
@@ -13,6 +14,9 @@ sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [16, 
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 limit = float(sys.argv[3]) if len(sys.argv) > 3 else 150
 cpu_limit = float(sys.argv[4]) if len(sys.argv) > 4 else 240
+lookahead = bool(int(os.environ.get("LOOKAHEAD", "0")))     # the last bounds two at a time (loop.py::solver_loop_pair)
+KW = dict(kv.split("=") for kv in os.environ.get("SOLVER_OPTS", "").split(",") if kv)
+KW = {k: int(v) for k, v in KW.items()}
 for m in sizes:
     g = WorldGrid.rect(m, m)
     e = Encoding.encode(PLATFORMS_DEFAULT, g)
@@ -36,7 +40,8 @@ for m in sizes:
     gpu = []
     for rep in range(reps):
         t0 = time.perf_counter()
-        hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=limit, make_solver=lambda: Mi355Sat())
+        hist = solver_loop_sweep(g, e, PlatformLimits({(1, 1): m}), out=lambda l: None, time_limit=limit, lookahead=lookahead,
+                                 make_solver=lambda half=False: Mi355Sat(**({"workers": 512} if half else {}), **KW))
         ok = hist[-1]["result"] == SolverResult.Unsat
         gpu.append((round(time.perf_counter() - t0, 2), [h["count"] for h in hist if h["count"]][-1] if ok else None,
                     [(h["k"], h["result"].name, h["count"], round(h["seconds"], 1)) for h in hist]))

@@ -33,7 +33,7 @@
 #define __forceinline__ inline
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local      /* (two emulated solvers may run in two host threads) */
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct int2 { int x, y; };
@@ -134,7 +134,7 @@ static inline bool __hip_atomic_compare_exchange_strong(volatile T* p, T* expect
     return false;
 }
 // dynamic LDS: one static 160 KiB block per (sequentially executed) workgroup
-#define HIP_DYNAMIC_SHARED(type, var) static type var[163840 / sizeof(type)];
+#define HIP_DYNAMIC_SHARED(type, var) static thread_local type var[163840 / sizeof(type)];
 
 // ---- runtime shims ------------------------------------------------------------------
 typedef int hipError_t;

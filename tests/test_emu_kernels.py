@@ -602,3 +602,21 @@ def test_emulated_deterministic_mode_repeats_itself():
         runs.append((st["conflicts"], st["propagations"], st["decisions"], st["shared_exported"], st["shared_imported"]))
         s.close()
     assert runs[0] == runs[1] and runs[0][0] > 0 and runs[0][3] > 0
+
+
+@pytest.mark.parametrize("terrain,pset,k0,kstar", [("ex1", "1x1", 6, 3), ("rect8x8", "1x1", 8, 4)])
+def test_emulated_lookahead_loop_is_the_sequential_loop(terrain, pset, k0, kstar):
+    """solver_loop_pair: the bound the reference would pose next and the one below it run side by side (two handles, two
+    host threads); what comes out is the reference's loop - its messages, valid layouts, the golden optimum and the
+    refuted bound."""
+    from timberborn_support_solver_amd import solver_loop_pair
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    lines = []
+    hist = solver_loop_pair(grid, enc, PlatformLimits({(1, 1): k0}), out=lines.append,
+                            make_solver=lambda: emu_solver(workers=3, slice_conflicts=20))
+    assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == kstar - 1
+    sat = [h for h in hist if h["result"] == SolverResult.Sat]
+    assert sat and sat[-1]["count"] == kstar and all(h["valid"] and h["count"] <= h["k"] for h in sat)
+    assert lines[-1] == "No solution found for the current constraints"
+    assert f"Solution found ({kstar} platforms total)" in lines and "Solution validation FAILED" not in lines

@@ -2280,10 +2280,10 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     ls.best_trail = st->best_trail; ls.n_rephase = st->n_rephase; ls.next_rephase = st->next_rephase;
     ls.rephase = prm.rephase == 1 || (prm.rephase == 2 && (wid & 1u));
     ls.import_pct = prm.import_pct > 0 ? (uint32_t)prm.import_pct : 50u;
-    ls.vivify = prm.vivify > 0 ? (uint32_t)prm.vivify : (prm.vivify == 0 ? 4u : 0u);
+    ls.vivify = prm.vivify > 0 ? (uint32_t)prm.vivify : 0u;      // (off by default since round 3)
     ls.next_vivify = st->next_vivify; ls.n_vivified = st->n_vivified; ls.n_viv_lits = st->n_viv_lits;
     // restart_k2_pct: every second worker uses this K instead (a portfolio of restart policies)
-    ls.restart_k = 0.01 * (double)(((wid & 1u) && prm.restart_k2_pct > 0) ? prm.restart_k2_pct : (prm.restart_k_pct > 0 ? prm.restart_k_pct : 80));
+    ls.restart_k = 0.01 * (double)(((wid & 1u) && prm.restart_k2_pct > 0) ? prm.restart_k2_pct : (prm.restart_k_pct > 0 ? prm.restart_k_pct : 100));
     const int n_assumps_reg = ls.n_assumps;
     MsShared sc = sh;     // private copies for the cold calls (their address is taken)
     MsLayout lc = L;

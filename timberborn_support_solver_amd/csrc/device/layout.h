@@ -203,8 +203,8 @@ struct MsParams {
     uint32_t share_interval;       // a worker with unseen records restarts to import them after this many conflicts
     uint32_t share_max_len;
     int32_t rephase;               // 0: off, 1: every worker rephases to its best assignment, 2: workers with an odd index
-    int32_t restart_k_pct;         // Glucose restart factor K in percent (0 = 80)
+    int32_t restart_k_pct;         // Glucose restart factor K in percent (0 = 100)
     int32_t restart_k2_pct;        // > 0: workers with an odd index use this K
-    int32_t vivify, pad5;          // learnt clauses vivified per pass (0 = 4, -1 = off)
+    int32_t vivify, pad5;          // learnt clauses vivified per pass (0 / -1 = off)
     int32_t import_pct;            // share (percent) of the exchanged clauses of >= 3 literals a worker attaches (0 = 50)
 };

@@ -66,8 +66,119 @@ def solver_loop(grid, encoding, limits, make_solver=None, out=print, on_interrup
     return history
 
 
+def solver_loop_pair(grid, encoding, limits, make_solver=None, out=print, on_interrupter=None):
+    """The reference's sequential loop (main.rs:290-346) with ONE bound of lookahead: while the bound k the reference
+    would pose next is being solved, the bound k - 1 runs beside it in a solver of its own (its own CNF, its own stream;
+    `make_solver(half=True)` gives each half of the fleet - on rect 28 / 32 half the default fleet decides a bound as
+    fast as the whole, profiles/r03_m_knob_sweep1.log).  Near the optimum the loop's last two bounds are the expensive
+    ones (the last model, then the refutation): this way they overlap.  What the caller sees is the reference's loop:
+    the same messages in the same order, records only for the bounds the sequential loop would have posed; a
+    speculative solve whose answer is implied by the other's is interrupted and dropped.
+      k SAT with count c  -> next bound c - 1: if that is k - 1 the running partner is promoted, else both restart
+      k UNSAT             -> done (the partner, a lower bound, is implied UNSAT)
+      k - 1 SAT (first)   -> k is implied SAT: its solve is dropped, the partner's model is the iteration's
+      k - 1 UNSAT (first) -> k decides alone: SAT means k is the optimum, and the loop ends with k - 1's refutation"""
+    import threading
+    k = limits.card_limits[(1, 1)]
+    history = []
+
+    def make(cnf):
+        if make_solver is None:      # half the default fleet each (1024 workers above 20 000 clauses, mi355sat.h)
+            return Mi355Sat(workers=512) if cnf.n_clauses > 20000 else Mi355Sat()
+        try:
+            return make_solver(half=True)
+        except TypeError:            # a factory without the keyword: whatever it makes, twice
+            return make_solver()
+
+    def start(bound):
+        cnf = encoding.with_limits_into_cnf(PlatformLimits({(1, 1): bound}))
+        solver = make(cnf)
+        thunk, interrupter = run_solver(solver, cnf)
+        if on_interrupter:
+            on_interrupter(interrupter)
+        job = {"k": bound, "solver": solver, "intr": interrupter, "done": threading.Event(), "t0": time.perf_counter()}
+
+        def work():
+            try:
+                job["result"] = thunk()[0]
+            except Exception as e:        # surfaces in the caller's thread
+                job["error"] = e
+            job["seconds"] = time.perf_counter() - job["t0"]
+            job["done"].set()
+
+        job["thread"] = threading.Thread(target=work, daemon=True)
+        job["thread"].start()
+        return job
+
+    def drop(job):
+        if job is None:
+            return
+        job["intr"].interrupt()
+        job["thread"].join()
+        job["solver"].close()
+
+    def finish(job):
+        job["thread"].join()
+        if "error" in job:
+            raise job["error"]
+        return job["result"]
+
+    a, b = start(k), (start(k - 1) if k >= 1 else None)
+    while True:
+        # wait for whichever decides something
+        while not a["done"].is_set() and not (b is not None and b["done"].is_set()):
+            a["done"].wait(0.005)
+        if not a["done"].is_set():      # the partner (k - 1) answered first
+            rb = finish(b)
+            if rb == SolverResult.Sat:   # then k is satisfiable too: the partner's model is this iteration's
+                drop(a)
+                a, b = b, None
+            elif rb == SolverResult.Unsat:      # k decides alone; remember the refutation
+                finish(a)
+                b["solver"].close()
+                b = {"k": b["k"], "refuted": True, "seconds": b["seconds"]}
+            else:                        # interrupted from outside
+                finish(a)
+                b["solver"].close()
+                b = None
+        ra = finish(a)
+        rec = {"k": a["k"], "result": ra, "count": None, "valid": None, "seconds": a["seconds"], "stats": a["solver"].stats()}
+        history.append(rec)
+        if ra != SolverResult.Sat:
+            out("No solution found for the current constraints" if ra == SolverResult.Unsat else "Solver interrupted")
+            a["solver"].close()
+            if b is not None and not b.get("refuted"):
+                drop(b)
+            return history
+        layout = PlatformLayout.from_assignment(a["solver"].full_solution(encoding.n_vars), encoding)
+        a["solver"].close()
+        count = layout.platform_count()
+        rec["count"], rec["layout"] = count, layout
+        if count == 0:
+            out("Found a solution with no platforms - aborting")
+            if b is not None and not b.get("refuted"):
+                drop(b)
+            return history
+        out(f"Solution found ({count} platforms total)")
+        for (w, h), n in sorted(layout.platform_stats().items()):
+            out(f"{w}x{h}: {n}")
+        rec["valid"] = layout.validate(grid).is_valid()
+        out("Solution validation OK" if rec["valid"] else "Solution validation FAILED")
+        nxt = count - 1
+        if b is not None and b.get("refuted") and b["k"] >= nxt:      # the next bound is refuted already
+            history.append({"k": nxt, "result": SolverResult.Unsat, "count": None, "valid": None, "seconds": b["seconds"], "stats": {}})
+            out("No solution found for the current constraints")
+            return history
+        if b is not None and not b.get("refuted") and b["k"] == nxt:
+            a, b = b, (start(nxt - 1) if nxt >= 1 else None)          # the partner is the next bound: promote it
+        else:
+            if b is not None and not b.get("refuted"):
+                drop(b)
+            a, b = start(nxt), (start(nxt - 1) if nxt >= 1 else None)
+
+
 def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_interrupter=None, time_limit=None,
-                      specialize_after=2.0):
+                      specialize_after=2.0, lookahead=False):
     """The same refinement as ONE batch: every bound k0, k0-1, ..., 0 is an assumption set over one
     CNF built for k0 (`with_limits_into_cnf(sweep=True)`), all solved concurrently on the device.  A SAT model
     with c platforms answers every bound >= c, an UNSAT bound every bound below it; those instances are
@@ -116,7 +227,7 @@ def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_in
 
     def on_deadline():
         expired.append(1)
-        for i in interrupters[-1:]:
+        for i in interrupters[-2:]:      # (with lookahead two solvers run at a time)
             i.interrupt()
 
     if time_limit is not None:   # the rest of the time budget holds for the sequential part as a whole
@@ -124,7 +235,10 @@ def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_in
         timer = threading.Timer(max(0.0, time_limit - (time.perf_counter() - t0)), on_deadline)
         timer.start()
     try:
-        rest = solver_loop(grid, encoding, PlatformLimits({(1, 1): best - 1}), make_solver=make_solver, out=out, on_interrupter=note)
+        if lookahead:
+            rest = solver_loop_pair(grid, encoding, PlatformLimits({(1, 1): best - 1}), make_solver=make_solver, out=out, on_interrupter=note)
+        else:
+            rest = solver_loop(grid, encoding, PlatformLimits({(1, 1): best - 1}), make_solver=make_solver, out=out, on_interrupter=note)
     finally:
         if timer:
             timer.cancel()
