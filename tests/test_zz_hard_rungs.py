@@ -14,8 +14,8 @@ from helpers import check_sat_answer, golden, make_grid, platform_defs
 from timberborn_support_solver_amd import Encoding, Mi355Sat, PlatformLimits, SolverResult
 
 HARD = golden("verdicts_hard.json")["verdicts"]
-# (terrain, k) -> stated time limit in seconds for the GPU.  Round-2/3 measurements: rect 26 k = 10 37-56 s,
-# rect 28 k = 11 38-64 s, rect 32 k = 14 157-183 s with the default fleet (1024 workers).
+# (terrain, k) -> stated time limit in seconds for the GPU.  Measured with the default fleet (1024 workers): round 2 rect 26
+# k = 10 37-56 s, rect 28 k = 11 38-64 s, rect 32 k = 14 157-183 s; end of round 3 10-17 s, 10-17 s, 16-27 s (profiles/r03_*).
 LIMITS = {("rect26x26", 10): 150, ("rect26x26", 11): 60, ("rect28x28", 11): 150, ("rect28x28", 12): 60, ("rect32x32", 14): 400}
 
 

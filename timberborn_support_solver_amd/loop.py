@@ -255,7 +255,7 @@ def frontier_weights(ks, res, best_c, unsat_k, rest=0.02):
     return [1.0 if k in (hi, lo) else rest for k in ks]
 
 
-def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limit, specialize_after=None):
+def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limit, specialize_after=None, stall=0.4):
     cnf = encoding.with_limits_into_cnf(PlatformLimits({(1, 1): k0}), sweep=True)
     ks = list(range(k0, -1, -1))
     sets = [([-int(cnf.card_outputs[k])] if k < len(cnf.card_outputs) else []) for k in ks]
@@ -276,6 +276,7 @@ def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limi
     solver.sweep_begin(sets)
     best_c, best_i, unsat_k, looked = None, None, -1, set()
     interrupted = specialize = False
+    t_progress = t0
     while True:
         res, _ = solver.sweep_step()
         for i, r in enumerate(res):
@@ -286,6 +287,7 @@ def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limi
                 c = PlatformLayout.from_assignment(solver.sweep_solution_of(i, encoding.n_vars), encoding).platform_count()
                 if best_c is None or c < best_c:
                     best_c, best_i = c, i
+                    t_progress = time.perf_counter()
         if best_c is not None and (unsat_k + 1 >= best_c or best_c == 0):
             break
         if all(r != SolverResult.Interrupted for r in res):
@@ -293,7 +295,12 @@ def _sweep_below(grid, encoding, k0, make_solver, out, on_interrupter, time_limi
         if flag or (time_limit is not None and time.perf_counter() - t0 > time_limit):
             interrupted = True
             break
-        if specialize_after is not None and time.perf_counter() - t0 > specialize_after:
+        # the batch is the way DOWN: it ends once it has stopped finding better layouts (no new best count for
+        # `stall` seconds), at the latest after three times `specialize_after`; `specialize_after` itself is how long
+        # it runs at least when it is still walking down
+        now = time.perf_counter()
+        if specialize_after is not None and ((now - t0 > specialize_after and now - t_progress > stall) or now - t0 > 3 * specialize_after
+                                             or (now - t0 > stall and now - t_progress > 2 * stall)):
             specialize = True
             break
         solver.sweep_drop([i for i, k in enumerate(ks) if res[i] == SolverResult.Interrupted and
