@@ -67,7 +67,7 @@ typedef struct mi355sat_opts {
     int32_t reduce_first;      /* conflicts before the first learnt-clause reduction; 0 = 2000 */
     int32_t reduce_inc;        /* growth of the reduction interval; 0 = 300 */
     int32_t lds_val;           /* assignment in LDS (2 bits/var): 0 auto, 1 force, -1 never */
-    int32_t max_groups;        /* queue literals propagated per BCP step: 1..16; 0 = 16 */
+    int32_t max_groups;        /* queue literals propagated per BCP step: 1..32; 0 = 32 */
     int32_t slice_ms;          /* wall-time bound of one kernel launch in ms (all workers stop together); 0 = default: 20 in a
                                   solve's first second of kernel time, then 50, after ten seconds 100 */
     int32_t cube_split;        /* 0 (default): portfolio, every worker of an instance searches the whole instance with its

@@ -109,6 +109,7 @@ static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T>
 static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 static inline int4 make_int4(int a, int b, int c, int d) { return int4{a, b, c, d}; }
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
 template <class T>
 static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T>

@@ -133,7 +133,9 @@ def _ring_worker(rank, world, port, q):
         res, _ = s.sweep_step()
         a, b = exchange_ring(s, "cpu")
         sent, taken, rounds = sent + a, taken + b, rounds + 1
-        done = torch.tensor([1 if (res[0].value or (sent and taken and rounds >= 3)) else 0], dtype=torch.int64)
+        st = s.stats()                                                  # (workers attach foreign records a slice after they arrive)
+        got = st["shared_imported"] + st["shared_imported_units"] > 0
+        done = torch.tensor([1 if (res[0].value or (sent and taken and got and rounds >= 3)) else 0], dtype=torch.int64)
         dist.all_reduce(done, op=dist.ReduceOp.MIN)                    # leave together
         if int(done[0]):
             break

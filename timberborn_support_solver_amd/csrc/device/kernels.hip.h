@@ -62,6 +62,9 @@ enum { PF_OFF = 0, PF_BIN, PF_TERN, PF_LONG, PF_CLOSE, PF_ANALYZE, PF_BACKJUMP, 
        PF_RES_STEPS = PF_N, PF_MIN_DEEP, PF_MIN_LOCAL, PF_MIN_NODES, PF_MIN_CALLS, PF_ALL };
 
 #define DEV __device__ __forceinline__
+#ifndef MS_TAIL_UNROLL
+#define MS_TAIL_UNROLL 2      // chunks of a clause tail examined per round trip (long_eval, phase B)
+#endif
 // cold paths are real calls: keeps them out of the hot loop's register allocation
 #define DEV_COLD __device__ __noinline__
 
@@ -127,6 +130,8 @@ struct Wk {
 #ifdef MS_PROFILE
     u64 prof[PF_ALL];          // phase cycles, then counts / sub-phases of conflict analysis
 #endif
+    LdsU32 tl;                 // owner lanes of the clause tails scanned together (64 words)
+    LdsI32 jd;                 // j / done of every group while the remainder of the watch lists is visited (2 x MS_MAX_GROUPS)
 };
 
 // Arrays are addressed through the kernel arguments (scalar registers / scalar loads), not through
@@ -174,6 +179,14 @@ DEV int lit_value(const Wk& w, const MsShared& sh, const MsLayout& L, int lit) {
     uint32_t x;
     if (LV) x = (w.lval[v >> 4] >> ((v & 15) * 2)) & 3u;
     else x = WKA(uint8_t, val)[v];
+    return (x & 2u) ? (int)((x ^ (uint32_t)lit) & 1u) : MS_VAL_UNDEF;
+}
+// (LV) A look-up in two halves: the word (an LDS read the caller issues unconditionally, together with its neighbours, so
+// that a group of look-ups costs ONE wait - a look-up under a lane condition compiles to a branch, a read and a wait
+// of its own) and the decoding of the literal's two bits.
+DEV uint32_t lval_word(const Wk& w, int lit) { return w.lval[lit >> 5]; }
+DEV int lval_decode(uint32_t word, int lit) {
+    const uint32_t x = word >> (uint32_t)(lit & 30);
     return (x & 2u) ? (int)((x ^ (uint32_t)lit) & 1u) : MS_VAL_UNDEF;
 }
 template <bool LV>
@@ -389,7 +402,9 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
     int size = (int)ch.size;
     Gp<const int32_t> cl = lits_base(w, sh, L, wt.x) + ch.start;
     uint32_t nl = 0;
-    if (live && vbl != MS_VAL_TRUE) {
+    const bool eval = live && vbl != MS_VAL_TRUE;
+    int r8 = -1;        // the first of the first MS_LANE_SCAN literals that is not false
+    if (eval) {
         other = (ww.x == fl) ? ww.y : ww.x;
         // the other watch and the first MS_LANE_SCAN literals (16-byte loads) + their values, issued together
         int ls[MS_LANE_SCAN], vs[MS_LANE_SCAN];
@@ -398,53 +413,117 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
             const int4 q = k < size ? (LV ? (k == 0 ? h0 : h1) : gld<int4>((Gp<const int4>)(cl + k))) : make_int4(fl, fl, fl, fl);
             ls[k] = q.x; ls[k + 1] = q.y; ls[k + 2] = q.z; ls[k + 3] = q.w;
         }
-        vo = lit_value<LV>(w, sh, L, other);
+        if (LV) {
+            uint32_t wv[MS_LANE_SCAN];
 #pragma unroll
-        for (int u = 0; u < MS_LANE_SCAN; u++) vs[u] = (u < size && ls[u] != fl && ls[u] != other) ? lit_value<LV>(w, sh, L, ls[u]) : MS_VAL_FALSE;
-        nl = 2;
-        if (vo == MS_VAL_TRUE) R.wt.y = other;
-        else {
-            // both watches false and the other one is being propagated by another group in
-            // this very step: the lower group handles the clause, the higher one re-queues
-            bool other_lower = false;
-            if (vo == MS_VAL_FALSE)
-                for (int gg = 0; gg < g; gg++) other_lower = other_lower || w.bfl[gg] == other;
-            if (other_lower) R.deferred = true;
-            else {
-                R.wt.y = other;
-                scanning = true;
+            for (int u = 0; u < MS_LANE_SCAN; u++) { ls[u] = u < size ? ls[u] : fl; wv[u] = lval_word(w, ls[u]); }
+            vo = lval_decode(lval_word(w, other), other);
 #pragma unroll
-                for (int u = MS_LANE_SCAN - 1; u >= 0; u--)
-                    if (vs[u] != MS_VAL_FALSE) r = ls[u];
-                nl += (uint32_t)(size < MS_LANE_SCAN ? size : MS_LANE_SCAN);
-                need_tail = r < 0 && size > MS_LANE_SCAN;
+            for (int u = 0; u < MS_LANE_SCAN; u++) vs[u] = (ls[u] != fl && ls[u] != other) ? lval_decode(wv[u], ls[u]) : MS_VAL_FALSE;
+        } else {
+            vo = lit_value<LV>(w, sh, L, other);
+#pragma unroll
+            for (int u = 0; u < MS_LANE_SCAN; u++) vs[u] = (u < size && ls[u] != fl && ls[u] != other) ? lit_value<LV>(w, sh, L, ls[u]) : MS_VAL_FALSE;
+        }
+#pragma unroll
+        for (int u = MS_LANE_SCAN - 1; u >= 0; u--)
+            if (vs[u] != MS_VAL_FALSE) r8 = ls[u];
+    }
+    // Both watches false and the other one is being propagated by another group in this very step: the lower group
+    // handles the clause, the higher one re-queues.  Whole wave, one asking lane at a time (there are few): lane i < g holds
+    // the literal group i propagates, a ballot says whether one of them is the asking lane's other watch.
+    bool other_lower = false;
+    {
+        u64 am = ballot(eval && vo == MS_VAL_FALSE);
+        if (am != 0) {
+            const int bflv = w.lane < MS_MAX_GROUPS ? w.bfl[w.lane] : 0;
+            for (; am != 0; am &= am - 1) {
+                const int f = first_lane(am);
+                const int of = bcast(other, f), gf = bcast(g, f);
+                const u64 mm = ballot(w.lane < gf && bflv == of);
+                if (w.lane == f) other_lower = mm != 0;
             }
         }
     }
-    // phase B (whole wave, one clause at a time): the tail of long clauses, 64 literals per load
-    for (u64 tm = ballot(need_tail); tm != 0; tm &= tm - 1) {
-        const int f = first_lane(tm);
-        const unsigned long long cp = (unsigned long long)cl;
-        Gp<const int32_t> clf = (Gp<const int32_t>)(((unsigned long long)(uint32_t)bcast((int)(cp >> 32), f) << 32) |
-                                                  (unsigned long long)(uint32_t)bcast((int)cp, f));
-        const int szf = bcast(size, f), flf = bcast(fl, f), of = bcast(other, f);
-        int found = -1;
-        for (int k0 = MS_LANE_SCAN; k0 < szf && found < 0; k0 += MS_WAVE) {
-            const int k = k0 + w.lane;
-            const int l = k < szf ? clf[k] : flf;
-            const bool ok = k < szf && l != flf && l != of && lit_value<LV>(w, sh, L, l) != MS_VAL_FALSE;
-            const u64 om = ballot(ok);
-            if (om) found = bcast(l, first_lane(om));
+    if (eval) {
+        nl = 2;
+        if (vo == MS_VAL_TRUE) R.wt.y = other;
+        else if (other_lower) R.deferred = true;
+        else {
+            R.wt.y = other;
+            scanning = true;
+            r = r8;
+            nl += (uint32_t)(size < MS_LANE_SCAN ? size : MS_LANE_SCAN);
+            need_tail = r < 0 && size > MS_LANE_SCAN;
         }
-        if (w.lane == f) { r = found; nl += (uint32_t)(szf - MS_LANE_SCAN); }
+    }
+    // The header of the list a moved watcher goes to ({base, size, cap, -}) is requested as soon as the new watch is
+    // known: for the lanes that found it among the first MS_LANE_SCAN literals that is before the tail scans, whose
+    // round trips then hide this one.
+    Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
+    const bool push_a = scanning && r >= 0;
+    int4 th = push_a ? gld<int4>((Gp<const int4>)&whdr[HX(r ^ 1)]) : make_int4(0, 0, 0, 0);
+    // phase B: the tails of long clauses.  T clauses need one: the wave splits into segments of 64 >> ceil(log2 T) lanes,
+    // one clause per segment, so that one round trip serves all of them (a learnt clause here has ~100 literals and two
+    // thirds of the steps have a tail to scan: one clause at a time was 14 % of a lone worker's cycles).
+    const u64 tm = ballot(need_tail);
+    if (tm != 0) {
+        const int T = popc64(tm);
+        const int lgT = T > 1 ? 32 - __builtin_clz((unsigned)(T - 1)) : 0, SL = MS_WAVE >> lgT;
+        const int myrank = popc64(tm & lanemask_lt(w.lane));
+        lds_fence();
+        if (need_tail) w.tl[myrank] = (uint32_t)w.lane;
+        lds_fence();
+        const int seg = w.lane >> (6 - lgT), sl2 = w.lane & (SL - 1);
+        bool open = seg < T;
+        const int own = open ? (int)w.tl[seg] : 0;
+        const unsigned long long cp = (unsigned long long)cl;
+        Gp<const int32_t> clf = (Gp<const int32_t>)(((unsigned long long)(uint32_t)bcast((int)(cp >> 32), own) << 32) |
+                                                  (unsigned long long)(uint32_t)bcast((int)cp, own));
+        const int szf = bcast(size, own), flf = bcast(fl, own), of = bcast(other, own);
+        const u64 segmask = (SL == MS_WAVE ? ~0ull : ((1ull << SL) - 1ull)) << (seg * SL);
+        int found = -1;
+        // MS_TAIL_UNROLL chunks per round: their loads (and, with the assignment in LDS, their look-ups) are in flight
+        // together, so a round costs one round trip whatever it covers
+        for (int k0 = MS_LANE_SCAN; ballot(open) != 0; k0 += MS_TAIL_UNROLL * SL) {
+            int lu[MS_TAIL_UNROLL];
+            bool oku[MS_TAIL_UNROLL];
+#pragma unroll
+            for (int u = 0; u < MS_TAIL_UNROLL; u++) {
+                const int k = k0 + u * SL + sl2;
+                lu[u] = (open && k < szf) ? clf[k] : flf;
+            }
+            if (LV) {
+                uint32_t wv[MS_TAIL_UNROLL];
+#pragma unroll
+                for (int u = 0; u < MS_TAIL_UNROLL; u++) wv[u] = lval_word(w, lu[u]);
+#pragma unroll
+                for (int u = 0; u < MS_TAIL_UNROLL; u++) oku[u] = lu[u] != flf && lu[u] != of && lval_decode(wv[u], lu[u]) != MS_VAL_FALSE;
+            } else {
+#pragma unroll
+                for (int u = 0; u < MS_TAIL_UNROLL; u++) oku[u] = lu[u] != flf && lu[u] != of && lit_value<LV>(w, sh, L, lu[u]) != MS_VAL_FALSE;
+            }
+            int fnd = -1;
+#pragma unroll
+            for (int u = 0; u < MS_TAIL_UNROLL; u++) {
+                const u64 om = ballot(oku[u]) & segmask;
+                const int lf = bcast(lu[u], om ? first_lane(om) : w.lane);
+                if (fnd < 0 && om) fnd = lf;
+            }
+            if (open) {
+                if (fnd >= 0) { found = fnd; open = false; }
+                else if (k0 + MS_TAIL_UNROLL * SL >= szf) open = false;
+            }
+        }
+        const int res = bcast(found, myrank << (6 - lgT));
+        if (need_tail) { r = res; nl += (uint32_t)(size - MS_LANE_SCAN); }
     }
     // phase C: move the watch, or report unit / conflict.  A moved watcher is appended to the list of its new literal;
     // lanes that append to the SAME list in this call rank themselves (a loop over the few distinct lists), so the
     // list's size is read and written with plain accesses: no read-modify-write leaves the wave.
     const bool push = scanning && r >= 0;
     const int t = r ^ 1;
-    Gp<MsWatchHdr> whdr = WKA(MsWatchHdr, whdr);
-    const int4 th = push ? gld<int4>((Gp<const int4>)&whdr[HX(t)]) : make_int4(0, 0, 0, 0);   // {base, size, cap, -}
+    if (push && !push_a) th = gld<int4>((Gp<const int4>)&whdr[HX(t)]);
     int rank = 0, cnt = 0;
     for (u64 pm = ballot(push); pm != 0;) {
         const int tf = bcast(t, first_lane(pm));
@@ -474,31 +553,51 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
     return R;
 }
 
-// Flat work distribution for the REMAINDER of long read-only lists: group g still has rem entries
-// (after its first S), described by two per-group words a, b.  Leaders publish (rem, a, b) in LDS,
-// lanes 0..15 scan, and afterwards lane `item` finds its (group, index) by walking the scan.  Returns
-// the total number of items.  w.hist layout: [0..16) rem, [16..32) a, [32..48) b, [48..64) inclusive scan.
+// Flat work distribution for the REMAINDER of long lists: group g still has rem entries (after its first S), described
+// by two per-group words a, b.  Leaders publish (rem, a, b) in LDS, lanes 0..MS_MAX_GROUPS-1 scan, and afterwards lane
+// `item` finds its (group, index) by walking the scan.  Returns the total number of items.
+// w.hist layout (M = MS_MAX_GROUPS): [0..M) rem, [M..2M) a, [2M..3M) b, [3M..4M) inclusive scan.
 DEV int flat_setup(Wk& w, int G, int g, int sl, int rem, int a, int b) {
     LdsU32 fs = w.hist;
     lds_fence();
-    if (sl == 0) { fs[g] = (uint32_t)rem; fs[16 + g] = (uint32_t)a; fs[32 + g] = (uint32_t)b; }
+    if (sl == 0) { fs[g] = (uint32_t)rem; fs[MS_MAX_GROUPS + g] = (uint32_t)a; fs[2 * MS_MAX_GROUPS + g] = (uint32_t)b; }
     lds_fence();
     int x = w.lane < G ? (int)fs[w.lane] : 0;
-    for (int o = 1; o < 16; o <<= 1) {
+    for (int o = 1; o < MS_MAX_GROUPS; o <<= 1) {
         int t = __shfl_up(x, o, 64);
         if (w.lane >= o) x += t;
     }
-    if (w.lane < 16) fs[48 + w.lane] = (uint32_t)x;
+    if (w.lane < MS_MAX_GROUPS) fs[3 * MS_MAX_GROUPS + w.lane] = (uint32_t)x;
     lds_fence();
-    return (int)fs[48 + G - 1];
+    return (int)fs[3 * MS_MAX_GROUPS + G - 1];
 }
-DEV void flat_item(const Wk& w, int G, int item, int& gg, int& idx, int& a, int& b) {
+// prev / next: the items before this list and up to its end (the list's item range is [prev, next)).
+// REGS: the whole scan is read in one go (slots of groups >= G hold the total, which no item reaches) and counted in
+// registers - a walk with one dependent LDS read per group cost a lone worker 5 % of its cycles; the 16-waves-per-CU
+// builds (128 VGPRs, already spilling) keep the walk: the 32 extra registers cost them 4 %.
+template <bool REGS>
+DEV void flat_item(const Wk& w, int G, int item, int& gg, int& idx, int& a, int& b, int& prev, int& next) {
     LdsU32 fs = w.hist;
     gg = 0;
-    while (gg < G - 1 && (int)fs[48 + gg] <= item) gg++;
-    idx = item - (gg ? (int)fs[48 + gg - 1] : 0);
-    a = (int)fs[16 + gg];
-    b = (int)fs[32 + gg];
+    if (REGS) {
+        int sc[MS_MAX_GROUPS];
+#pragma unroll
+        for (int k = 0; k < MS_MAX_GROUPS; k++) sc[k] = (int)fs[3 * MS_MAX_GROUPS + k];
+#pragma unroll
+        for (int k = 0; k < MS_MAX_GROUPS - 1; k++) gg += sc[k] <= item ? 1 : 0;
+    } else {
+        while (gg < G - 1 && (int)fs[3 * MS_MAX_GROUPS + gg] <= item) gg++;
+    }
+    prev = gg ? (int)fs[3 * MS_MAX_GROUPS + gg - 1] : 0;
+    next = (int)fs[3 * MS_MAX_GROUPS + gg];
+    idx = item - prev;
+    a = (int)fs[MS_MAX_GROUPS + gg];
+    b = (int)fs[2 * MS_MAX_GROUPS + gg];
+}
+template <bool REGS>
+DEV void flat_item(const Wk& w, int G, int item, int& gg, int& idx, int& a, int& b) {
+    int prev, next;
+    flat_item<REGS>(w, G, item, gg, idx, a, b, prev, next);
 }
 
 // Unit propagation to fixpoint.  Returns true on conflict (w.confl_*).
@@ -515,7 +614,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         PROF_DECL
         // ---- split the wave into G groups of S lanes, one queue literal per group
         const int qlen = w.trail_n - w.qhead;
-        int lg = qlen >= 16 ? 4 : (qlen >= 8 ? 3 : (qlen >= 4 ? 2 : (qlen >= 2 ? 1 : 0)));
+        int lg = qlen >= 32 ? 5 : qlen >= 16 ? 4 : (qlen >= 8 ? 3 : (qlen >= 4 ? 2 : (qlen >= 2 ? 1 : 0)));
         while ((1 << lg) > w.max_groups) lg--;
         const int G = 1 << lg, S = MS_WAVE >> lg;
         const int g = w.lane >> (6 - lg), sl = w.lane & (S - 1);
@@ -543,10 +642,20 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         // whose blocker is not true (assignment in LDS: the blockers' values are known at once) or, with the
         // assignment in HBM, speculatively of every live watcher's clause
         const bool live0 = sl < n && wt0.x >= 0;
-        const int vq = act_b ? lit_value<LV>(w, sh, L, q0) : MS_VAL_TRUE;
-        const int vb = act_t ? lit_value<LV>(w, sh, L, pr0.x) : MS_VAL_TRUE;
-        const int vc = act_t ? lit_value<LV>(w, sh, L, pr0.y) : MS_VAL_TRUE;
-        const int vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
+        int vq, vb, vc, vbl0;
+        if (LV) {   // (inactive lanes look literal 0 up: four reads, one wait)
+            const int bl = live0 ? wt0.y : 0;
+            const uint32_t xq = lval_word(w, q0), xb = lval_word(w, pr0.x), xc = lval_word(w, pr0.y), xl = lval_word(w, bl);
+            vq = act_b ? lval_decode(xq, q0) : MS_VAL_TRUE;
+            vb = act_t ? lval_decode(xb, pr0.x) : MS_VAL_TRUE;
+            vc = act_t ? lval_decode(xc, pr0.y) : MS_VAL_TRUE;
+            vbl0 = live0 ? lval_decode(xl, bl) : MS_VAL_TRUE;
+        } else {
+            vq = act_b ? lit_value<LV>(w, sh, L, q0) : MS_VAL_TRUE;
+            vb = act_t ? lit_value<LV>(w, sh, L, pr0.x) : MS_VAL_TRUE;
+            vc = act_t ? lit_value<LV>(w, sh, L, pr0.y) : MS_VAL_TRUE;
+            vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
+        }
         const int2 ww0 = (live0 && (!LV || vbl0 != MS_VAL_TRUE)) ? gld<int2>((Gp<const int2>)&wl[wt0.x]) : make_int2(0, 0);
         int4 h00 = make_int4(0, 0, 0, 0), h01 = make_int4(0, 0, 0, 0);
         if (LV && live0 && vbl0 != MS_VAL_TRUE) {
@@ -616,7 +725,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                     const int item = base + w.lane;
                     const bool act = item < total;
                     int gg = 0, i = 0, fb0 = 0, ffl = 0;
-                    if (act) flat_item(w, G, item, gg, i, fb0, ffl);
+                    if (act) flat_item<LV>(w, G, item, gg, i, fb0, ffl);
                     const int q = act ? bin_lits[(uint32_t)fb0 + (uint32_t)S + (uint32_t)i] : 0;
                     const int v = act ? lit_value<LV>(w, sh, L, q) : MS_VAL_TRUE;
                     w.c_watch += (uint32_t)popc64(ballot(act));
@@ -641,7 +750,7 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                     const int item = base + w.lane;
                     const bool act = item < total;
                     int gg = 0, i = 0, ft0 = 0, ffl = 0;
-                    if (act) flat_item(w, G, item, gg, i, ft0, ffl);
+                    if (act) flat_item<LV>(w, G, item, gg, i, ft0, ffl);
                     const uint32_t e = (uint32_t)ft0 + (uint32_t)S + (uint32_t)i;
                     const int2 pr = act ? gld<int2>(tern_pairs + e) : make_int2(0, 0);
                     const int xb = act ? lit_value<LV>(w, sh, L, pr.x) : MS_VAL_TRUE;
@@ -664,50 +773,71 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                 }
             }
         }
-        // ---- the rest of long watch lists: one list at a time, 64 watchers per iteration ----
-        for (u64 rm = ballot(n > S && sl == 0); rm != 0 && !any_cf && w.status == MS_ST_RUNNING; rm &= rm - 1) {
-            const int lf = first_lane(rm);                 // leader lane of the group that owns this list
-            const int gl = lf >> (6 - lg);
-            const int fl_l = bcast(fl, lf), n_l = bcast(n, lf);
-            const uint32_t wb_l = (uint32_t)bcast((int)wb, lf);
-            int j_l = bcast(j, lf), done_l = S;
-            for (int i0 = S; i0 < n_l && !any_cf && w.status == MS_ST_RUNNING; i0 += MS_WAVE) {
-                const int i = i0 + w.lane;
-                const bool act = i < n_l;
-                const int4 wt = act ? gld<int4>(pool + (wb_l + i)) : make_int4(-1, 0, 0, 0);
-                const bool live = act && wt.x >= 0;
-                const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
-                const int2 ww = (live && (!LV || vbl != MS_VAL_TRUE)) ? gld<int2>((Gp<const int2>)&wl[wt.x]) : make_int2(0, 0);
-                int4 h0 = make_int4(0, 0, 0, 0), h1 = make_int4(0, 0, 0, 0);
-                if (LV && live && vbl != MS_VAL_TRUE) {
-                    Gp<const int32_t> clh = lits_base(w, sh, L, wt.x) + (uint32_t)wt.z;
-                    h0 = *(Gp<const int4>)clh;
-                    if (wt.w > 4) h1 = *(Gp<const int4>)(clh + 4);
+        // ---- the rest of long watch lists, spread flat over all 64 lanes like the binary and ternary remainders: ONE
+        // chain of round trips (watchers -> watched pairs and clause heads -> tails -> target headers) per 64 watchers
+        // of any list instead of one per list (a lone worker spent a quarter of its steps here, 1.8 chains each).  Kept
+        // watchers are compacted in place per list - the lanes of a list are contiguous in a batch - and j / done of
+        // every group live in LDS while the loop runs.
+        {
+            const int rem = n > S ? n - S : 0;
+            if (!any_cf && w.status == MS_ST_RUNNING && ballot(rem > 0) != 0) {
+                const int total = flat_setup(w, G, g, sl, rem, (int)wb, fl);
+                if (sl == 0) { w.jd[g] = j; w.jd[MS_MAX_GROUPS + g] = done; }
+                lds_fence();
+                for (int base = 0; base < total && !any_cf && w.status == MS_ST_RUNNING; base += MS_WAVE) {
+                    const int item = base + w.lane;
+                    const bool act = item < total;
+                    int gg = 0, ix = 0, fwb = 0, ffl = 0, prev = 0, next = 0;
+                    if (act) flat_item<LV>(w, G, item, gg, ix, fwb, ffl, prev, next);
+                    const int i = S + ix;
+                    const int4 wt = act ? gld<int4>(pool + ((uint32_t)fwb + (uint32_t)i)) : make_int4(-1, 0, 0, 0);
+                    const bool live = act && wt.x >= 0;
+                    const int vbl = live ? lit_value<LV>(w, sh, L, wt.y) : MS_VAL_TRUE;
+                    const int2 ww = (live && (!LV || vbl != MS_VAL_TRUE)) ? gld<int2>((Gp<const int2>)&wl[wt.x]) : make_int2(0, 0);
+                    int4 h0 = make_int4(0, 0, 0, 0), h1 = make_int4(0, 0, 0, 0);
+                    if (LV && live && vbl != MS_VAL_TRUE) {
+                        Gp<const int32_t> clh = lits_base(w, sh, L, wt.x) + (uint32_t)wt.z;
+                        h0 = *(Gp<const int4>)clh;
+                        if (wt.w > 4) h1 = *(Gp<const int4>)(clh + 4);
+                    }
+                    w.c_watch += (uint32_t)popc64(ballot(live));
+                    LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, ffl, gg, h0, h1);
+                    w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
+                    const u64 km = ballot(R.keep);
+                    wave_fence();
+                    // this lane's list occupies lanes [s0, s1) of the batch
+                    const int s0 = prev > base ? prev - base : 0, s1 = next - base < MS_WAVE ? next - base : MS_WAVE;
+                    const u64 segm = act ? (s1 >= MS_WAVE ? ~0ull : ((1ull << s1) - 1ull)) & ~((1ull << s0) - 1ull) : 0ull;
+                    const int jold = act ? w.jd[gg] : 0;
+                    {
+                        const int d = jold + popc64(km & segm & lanemask_lt(w.lane));
+                        if (R.keep && (d != i || R.wt.y != wt.y)) pool[(uint32_t)fwb + (uint32_t)d] = R.wt;
+                    }
+                    lds_fence();
+                    if (act && w.lane == s0) {
+                        w.jd[gg] = jold + popc64(km & segm);
+                        w.jd[MS_MAX_GROUPS + gg] = S + ((next < base + MS_WAVE ? next : base + MS_WAVE) - prev);
+                    }
+                    lds_fence();
+                    const u64 dm = ballot(R.deferred);
+                    if (dm) defer_g = min(defer_g, bcast(gg, first_lane(dm)));
+                    repair_overflow(w, sh, L);
+                    commit_implications<LV>(w, sh, L, R.want, R.imp, wt.x, lost, (uint32_t)wt.z, (uint32_t)wt.w);
+                    const u64 cm = ballot(R.cf || lost);
+                    if (cm) {
+                        const int f = first_lane(cm);
+                        any_cf = true;
+                        w.confl_kind = 1;
+                        w.confl_cref = bcast(wt.x, f);
+                        w.confl_a = bcast(ffl, f);
+                        w.confl_b = bcast(wt.z, f);
+                        w.confl_c = bcast(wt.w, f);
+                    }
                 }
-                w.c_watch += (uint32_t)popc64(ballot(live));
-                LongRes R = long_eval<LV>(w, sh, L, wt, live, vbl, ww, fl_l, gl, h0, h1);
-                w.c_move += (uint32_t)popc64(ballot(R.live && !R.keep));
-                const u64 km = ballot(R.keep);
-                wave_fence();
-                {
-                    const int d = j_l + popc64(km & lanemask_lt(w.lane));
-                    if (R.keep && (d != i || R.wt.y != wt.y)) pool[wb_l + d] = R.wt;
-                }
-                j_l += popc64(km);
-                done_l = min(n_l, i0 + MS_WAVE);
-                if (ballot(R.deferred)) defer_g = min(defer_g, gl);
-                repair_overflow(w, sh, L);
-                commit_implications<LV>(w, sh, L, R.want, R.imp, wt.x, lost, (uint32_t)wt.z, (uint32_t)wt.w);
-                const u64 cm = ballot(R.cf || lost);
-                if (cm) {
-                    any_cf = true;
-                    w.confl_kind = 1;
-                    w.confl_cref = bcast(wt.x, first_lane(cm));
-                    w.confl_b = bcast(wt.z, first_lane(cm));
-                    w.confl_c = bcast(wt.w, first_lane(cm));
-                }
+                lds_fence();
+                j = w.jd[g];
+                done = w.jd[MS_MAX_GROUPS + g];
             }
-            if (g == gl) { j = j_l; done = done_l; }
         }
         // close each group's list: fully visited -> new size; interrupted -> tombstone the gap
         // between the compacted prefix and the first unvisited entry
@@ -2233,7 +2363,9 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     constexpr bool ONE = WPS == 1;
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
-    __shared__ uint32_t s_hist[64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[4 * MS_MAX_GROUPS < 64 ? 64 : 4 * MS_MAX_GROUPS];
+    __shared__ uint32_t s_tl[MS_WAVE];
+    __shared__ int32_t s_jd[2 * MS_MAX_GROUPS];
     __shared__ uint32_t s_lbdq[64];
     __shared__ int32_t s_bfl[MS_MAX_GROUPS];
     __shared__ uint32_t s_ov;
@@ -2245,7 +2377,7 @@ __global__ __launch_bounds__(MS_WAVE, WPS) void ms_search_kernel(MsShared sh, Ms
     Wk w;
     w.lane = (int)threadIdx.x;
     w.sortbuf = (LdsU32)s_sort; w.sort_n = WPS <= 2 ? MS_SORT_N : 0;
-    w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl;
+    w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl; w.tl = (LdsU32)s_tl; w.jd = (LdsI32)s_jd;
     w.lseen = w.lval + ((sh.n_vars + 15) >> 4);   // (LV) three bitmaps behind the assignment words
     w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);
     w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
@@ -2383,7 +2515,9 @@ template <bool LV>
 __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
-    __shared__ uint32_t s_hist[64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[4 * MS_MAX_GROUPS < 64 ? 64 : 4 * MS_MAX_GROUPS];
+    __shared__ uint32_t s_tl[MS_WAVE];
+    __shared__ int32_t s_jd[2 * MS_MAX_GROUPS];
     __shared__ int32_t s_bfl[MS_MAX_GROUPS];
     __shared__ uint32_t s_ov;
     __shared__ uint32_t s_mcnt;
@@ -2392,7 +2526,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_bcp_kernel(MsShared sh, MsLayout L
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl;
+    w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl; w.tl = (LdsU32)s_tl; w.jd = (LdsI32)s_jd;
     w.lseen = w.lval + ((sh.n_vars + 15) >> 4);   // (no analysis in this kernel; the level bitmaps are still maintained)
     w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);
     w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);
@@ -2437,7 +2571,9 @@ template <bool LV>
 __global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout L, char* slabs, MsParams prm) {
     __shared__ int32_t s_ring[MS_LDS_RING];
     __shared__ uint32_t s_claim[MS_CLAIM_SLOTS];
-    __shared__ uint32_t s_hist[64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[4 * MS_MAX_GROUPS < 64 ? 64 : 4 * MS_MAX_GROUPS];
+    __shared__ uint32_t s_tl[MS_WAVE];
+    __shared__ int32_t s_jd[2 * MS_MAX_GROUPS];
     __shared__ int32_t s_bfl[MS_MAX_GROUPS];
     __shared__ uint32_t s_ov;
     __shared__ uint32_t s_mcnt;
@@ -2446,7 +2582,7 @@ __global__ __launch_bounds__(MS_WAVE) void ms_probe_kernel(MsShared sh, MsLayout
     if (wid >= prm.n_workers) return;
     Wk w;
     w.lane = (int)threadIdx.x;
-    w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl;
+    w.ring = (LdsI32)s_ring; w.claim = (LdsU32)s_claim; w.ov_cnt = (LdsU32)&s_ov; w.hist = (LdsU32)s_hist; w.lval = (LdsU32)s_lval; w.bfl = (LdsI32)s_bfl; w.tl = (LdsU32)s_tl; w.jd = (LdsI32)s_jd;
     w.lseen = w.lval + ((sh.n_vars + 15) >> 4);
     w.lcur = w.lseen + ((sh.n_vars + 31) >> 5);
     w.lzero = w.lcur + ((sh.n_vars + 31) >> 5);

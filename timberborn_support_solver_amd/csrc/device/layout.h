@@ -22,7 +22,7 @@
 #define MS_CLAIM_SLOTS 256        // per-wave implication claim set in LDS (<= 192 candidates per commit)
 #define MS_OVERFLOW_CAP 192       // watcher pushes that found their list full, per chunk
 #define MS_LBDQ 50                // Glucose restart window
-#define MS_MAX_GROUPS 16          // queue literals propagated per step (lane groups per wave)
+#define MS_MAX_GROUPS 32          // queue literals propagated per step (lane groups per wave)
 #define MS_SPLIT_MAX 8            // decisions a worker offers per slice for splitting its cube
 // Learnt-clause exchange between the workers of one GPU: fixed 128-byte records
 //   word 0 = size | lbd << 6 | producer << 14,  words 1..31 = literals
