@@ -181,12 +181,19 @@ DEV int lit_value(const Wk& w, const MsShared& sh, const MsLayout& L, int lit) {
     else x = WKA(uint8_t, val)[v];
     return (x & 2u) ? (int)((x ^ (uint32_t)lit) & 1u) : MS_VAL_UNDEF;
 }
-// (LV) A look-up in two halves: the word (an LDS read the caller issues unconditionally, together with its neighbours, so
-// that a group of look-ups costs ONE wait - a look-up under a lane condition compiles to a branch, a read and a wait
-// of its own) and the decoding of the literal's two bits.
-DEV uint32_t lval_word(const Wk& w, int lit) { return w.lval[lit >> 5]; }
-DEV int lval_decode(uint32_t word, int lit) {
-    const uint32_t x = word >> (uint32_t)(lit & 30);
+// A look-up in two halves: the fetch (the LDS word holding the variable's two bits, or its byte in the slab) and the
+// decoding of the literal's value.  Callers with several look-ups to make issue all the fetches UNCONDITIONALLY and
+// back to back (lanes with nothing to look up fetch a harmless literal), so that a group of look-ups costs ONE wait:
+// a look-up under a lane condition compiles to a branch with a load and a wait of its own - eight clause literals were
+// eight dependent round trips (to LDS, or, with the assignment in the slab, to the L2 / HBM).
+template <bool LV>
+DEV uint32_t val_fetch(const Wk& w, const MsShared& sh, const MsLayout& L, int lit) {
+    if (LV) return w.lval[lit >> 5];
+    return (uint32_t)WKA(uint8_t, val)[lit >> 1];
+}
+template <bool LV>
+DEV int val_decode(uint32_t raw, int lit) {
+    const uint32_t x = LV ? raw >> (uint32_t)(lit & 30) : raw;
     return (x & 2u) ? (int)((x ^ (uint32_t)lit) & 1u) : MS_VAL_UNDEF;
 }
 template <bool LV>
@@ -413,17 +420,13 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
             const int4 q = k < size ? (LV ? (k == 0 ? h0 : h1) : gld<int4>((Gp<const int4>)(cl + k))) : make_int4(fl, fl, fl, fl);
             ls[k] = q.x; ls[k + 1] = q.y; ls[k + 2] = q.z; ls[k + 3] = q.w;
         }
-        if (LV) {
+        {
             uint32_t wv[MS_LANE_SCAN];
 #pragma unroll
-            for (int u = 0; u < MS_LANE_SCAN; u++) { ls[u] = u < size ? ls[u] : fl; wv[u] = lval_word(w, ls[u]); }
-            vo = lval_decode(lval_word(w, other), other);
+            for (int u = 0; u < MS_LANE_SCAN; u++) { ls[u] = u < size ? ls[u] : fl; wv[u] = val_fetch<LV>(w, sh, L, ls[u]); }
+            vo = val_decode<LV>(val_fetch<LV>(w, sh, L, other), other);
 #pragma unroll
-            for (int u = 0; u < MS_LANE_SCAN; u++) vs[u] = (ls[u] != fl && ls[u] != other) ? lval_decode(wv[u], ls[u]) : MS_VAL_FALSE;
-        } else {
-            vo = lit_value<LV>(w, sh, L, other);
-#pragma unroll
-            for (int u = 0; u < MS_LANE_SCAN; u++) vs[u] = (u < size && ls[u] != fl && ls[u] != other) ? lit_value<LV>(w, sh, L, ls[u]) : MS_VAL_FALSE;
+            for (int u = 0; u < MS_LANE_SCAN; u++) vs[u] = (ls[u] != fl && ls[u] != other) ? val_decode<LV>(wv[u], ls[u]) : MS_VAL_FALSE;
         }
 #pragma unroll
         for (int u = MS_LANE_SCAN - 1; u >= 0; u--)
@@ -493,15 +496,12 @@ DEV LongRes long_eval(Wk& w, const MsShared& sh, const MsLayout& L, int4 wt, boo
                 const int k = k0 + u * SL + sl2;
                 lu[u] = (open && k < szf) ? clf[k] : flf;
             }
-            if (LV) {
+            {
                 uint32_t wv[MS_TAIL_UNROLL];
 #pragma unroll
-                for (int u = 0; u < MS_TAIL_UNROLL; u++) wv[u] = lval_word(w, lu[u]);
+                for (int u = 0; u < MS_TAIL_UNROLL; u++) wv[u] = val_fetch<LV>(w, sh, L, lu[u]);
 #pragma unroll
-                for (int u = 0; u < MS_TAIL_UNROLL; u++) oku[u] = lu[u] != flf && lu[u] != of && lval_decode(wv[u], lu[u]) != MS_VAL_FALSE;
-            } else {
-#pragma unroll
-                for (int u = 0; u < MS_TAIL_UNROLL; u++) oku[u] = lu[u] != flf && lu[u] != of && lit_value<LV>(w, sh, L, lu[u]) != MS_VAL_FALSE;
+                for (int u = 0; u < MS_TAIL_UNROLL; u++) oku[u] = lu[u] != flf && lu[u] != of && val_decode<LV>(wv[u], lu[u]) != MS_VAL_FALSE;
             }
             int fnd = -1;
 #pragma unroll
@@ -629,9 +629,14 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         const int n = (int)wh.size;
         // round trip 1: the first chunk of all three lists
         const bool act_b = (uint32_t)sl < nb, act_t = (uint32_t)sl < nt;
-        const int q0 = act_b ? bin_lits[b0 + sl] : 0;
-        const int2 pr0 = act_t ? gld<int2>(tern_pairs + (t0 + sl)) : make_int2(0, 0);
-        const int4 wt0 = sl < n ? gld<int4>(pool + (wb + sl)) : make_int4(-1, 0, 0, 0);
+        // (three unconditional loads - lanes beyond the end of a list read entry 0 of the array and drop it: under lane
+        // conditions the compiler waited for the first two before it issued the third, a round trip of its own)
+        const int q0r = bin_lits[act_b ? b0 + (uint32_t)sl : 0u];
+        const int2 pr0r = gld<int2>(tern_pairs + (act_t ? t0 + (uint32_t)sl : 0u));
+        const int4 wt0r = gld<int4>(pool + (sl < n ? wb + (uint32_t)sl : 0u));
+        const int q0 = act_b ? q0r : 0;
+        const int2 pr0 = act_t ? pr0r : make_int2(0, 0);
+        const int4 wt0 = sl < n ? wt0r : make_int4(-1, 0, 0, 0);
         w.qhead += G;
         w.c_props += (uint32_t)G;
         w.c_steps++;
@@ -642,20 +647,14 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
         // whose blocker is not true (assignment in LDS: the blockers' values are known at once) or, with the
         // assignment in HBM, speculatively of every live watcher's clause
         const bool live0 = sl < n && wt0.x >= 0;
-        int vq, vb, vc, vbl0;
-        if (LV) {   // (inactive lanes look literal 0 up: four reads, one wait)
-            const int bl = live0 ? wt0.y : 0;
-            const uint32_t xq = lval_word(w, q0), xb = lval_word(w, pr0.x), xc = lval_word(w, pr0.y), xl = lval_word(w, bl);
-            vq = act_b ? lval_decode(xq, q0) : MS_VAL_TRUE;
-            vb = act_t ? lval_decode(xb, pr0.x) : MS_VAL_TRUE;
-            vc = act_t ? lval_decode(xc, pr0.y) : MS_VAL_TRUE;
-            vbl0 = live0 ? lval_decode(xl, bl) : MS_VAL_TRUE;
-        } else {
-            vq = act_b ? lit_value<LV>(w, sh, L, q0) : MS_VAL_TRUE;
-            vb = act_t ? lit_value<LV>(w, sh, L, pr0.x) : MS_VAL_TRUE;
-            vc = act_t ? lit_value<LV>(w, sh, L, pr0.y) : MS_VAL_TRUE;
-            vbl0 = live0 ? lit_value<LV>(w, sh, L, wt0.y) : MS_VAL_TRUE;
-        }
+        // (inactive lanes look literal 0 up: four fetches, one wait)
+        const int bl0 = live0 ? wt0.y : 0;
+        const uint32_t xq = val_fetch<LV>(w, sh, L, q0), xb = val_fetch<LV>(w, sh, L, pr0.x), xc = val_fetch<LV>(w, sh, L, pr0.y),
+                       xl = val_fetch<LV>(w, sh, L, bl0);
+        const int vq = act_b ? val_decode<LV>(xq, q0) : MS_VAL_TRUE;
+        const int vb = act_t ? val_decode<LV>(xb, pr0.x) : MS_VAL_TRUE;
+        const int vc = act_t ? val_decode<LV>(xc, pr0.y) : MS_VAL_TRUE;
+        const int vbl0 = live0 ? val_decode<LV>(xl, bl0) : MS_VAL_TRUE;
         const int2 ww0 = (live0 && (!LV || vbl0 != MS_VAL_TRUE)) ? gld<int2>((Gp<const int2>)&wl[wt0.x]) : make_int2(0, 0);
         int4 h00 = make_int4(0, 0, 0, 0), h01 = make_int4(0, 0, 0, 0);
         if (LV && live0 && vbl0 != MS_VAL_TRUE) {
@@ -753,8 +752,9 @@ DEV bool propagate(Wk& w, const MsShared& sh, const MsLayout& L) {
                     if (act) flat_item<LV>(w, G, item, gg, i, ft0, ffl);
                     const uint32_t e = (uint32_t)ft0 + (uint32_t)S + (uint32_t)i;
                     const int2 pr = act ? gld<int2>(tern_pairs + e) : make_int2(0, 0);
-                    const int xb = act ? lit_value<LV>(w, sh, L, pr.x) : MS_VAL_TRUE;
-                    const int xc = act ? lit_value<LV>(w, sh, L, pr.y) : MS_VAL_TRUE;
+                    const uint32_t rb = val_fetch<LV>(w, sh, L, pr.x), rc = val_fetch<LV>(w, sh, L, pr.y);   // (inactive lanes: literal 0)
+                    const int xb = act ? val_decode<LV>(rb, pr.x) : MS_VAL_TRUE;
+                    const int xc = act ? val_decode<LV>(rc, pr.y) : MS_VAL_TRUE;
                     w.c_watch += (uint32_t)popc64(ballot(act));
                     const bool sat = xb == MS_VAL_TRUE || xc == MS_VAL_TRUE;
                     const bool cf = !sat && xb == MS_VAL_FALSE && xc == MS_VAL_FALSE;
