@@ -956,7 +956,9 @@ DEV int pick_branch_var(Wk& w, const MsShared& sh, const MsLayout& L) {
         bool ok = false;
         if (w.lane < width && idx >= 0) {
             v = vm_order[idx];
-            ok = VMPOS[v] == idx && lit_value<LV>(w, sh, L, 2 * v) == MS_VAL_UNDEF;
+            const int pos = VMPOS[v];                                  // (both look-ups in flight together)
+            const uint32_t raw = val_fetch<LV>(w, sh, L, 2 * v);
+            ok = pos == idx && val_decode<LV>(raw, 2 * v) == MS_VAL_UNDEF;
         }
         u64 m = ballot(ok);
         if (m) {
@@ -1382,21 +1384,31 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
                 if (index < 0) { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
             }
         } else {
-            // 16 entries first (each costs a random variable-record line and the next one is usually close), the
-            // whole wave only when those miss
-            for (int width = 16;; width = MS_WAVE) {
-                int i = index - w.lane;
-                const bool in = w.lane < width && i >= 0;
-                int l = in ? WKA(int32_t, trail)[i] : 0;
-                bool ok = in && vrec[l >> 1].seen;
-                u64 m = ballot(ok);
+            // The marks are bytes in the variable records here.  A chunk of 64 trail entries stays in registers across
+            // resolution steps (lane i holds position chunk_hi - i); the 16 positions below `index` are tested first
+            // (each costs a random record line and the next marked literal is usually close), the rest of the chunk
+            // only when those miss.  The lane that finds p has loaded p's whole record - its reason and where the
+            // reason's literals are - so the step needs no round trip of its own for that.
+            bool wide = false;
+            for (;;) {
+                if (chunk_hi < 0 || index > chunk_hi || index <= chunk_hi - MS_WAVE) {
+                    chunk_hi = index;
+                    const int i = chunk_hi - w.lane;
+                    chunk_l = i >= 0 ? WKA(int32_t, trail)[i] : 0;
+                    wide = false;
+                }
+                const int pos = chunk_hi - w.lane;
+                const bool in = pos >= 0 && pos <= index && (wide || pos > index - 16);
+                if (in) c_rec = vrec[chunk_l >> 1];
+                const u64 m = ballot(in && c_rec.seen);
                 if (m) {
-                    int f = first_lane(m);
-                    index -= f;
-                    p = bcast(l, f);
+                    const int f = first_lane(m);
+                    index = chunk_hi - f;
+                    p = bcast(chunk_l, f);
                     break;
                 }
-                index -= width;
+                if (!wide && index - 16 > chunk_hi - MS_WAVE) { wide = true; continue; }    // the rest of this chunk
+                index = chunk_hi - MS_WAVE;
                 if (index < 0) { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
             }
         }
@@ -1444,14 +1456,14 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
             else { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
             continue;
         }
-        const MsVarRec pr = VREC[v];       // reason and, for a long reason, where its literals are: one round trip
-        const int r = uni(pr.reason);
+        const int fp = chunk_hi - (index + 1);      // the lane that holds p and its record
+        const int r = bcast(c_rec.reason, fp);
         wave_fence();
         if (w.lane == 0) seen_clr<LV>(w, sh, L, v);
         lds_fence();
         path_c--;
         if (path_c <= 0) break;
-        if (r >= 0) { kind = 1; cref = r; bb = uni((int)pr.start); bc = uni((int)pr.size); }
+        if (r >= 0) { kind = 1; cref = r; bb = bcast((int)c_rec.start, fp); bc = bcast((int)c_rec.size, fp); }
         else if (MS_IS_TERN_REASON(r)) {
             const int e = MS_TERN_REASON_ENTRY(r);
             const int2 pr = ((Gp<const int2>)sh.tern_pairs)[e];
