@@ -153,7 +153,7 @@ typedef struct mi355sat_stats_t {
     uint64_t kernel_launches;
     uint64_t n_deq, n_watch, n_cl_lit, n_move, n_enq;
     uint64_t n_sat, n_unsat, n_terminated; /* rustsat SolverStats: results returned so far */
-    uint64_t bcp_steps;        /* BCP steps; each propagates up to 16 queue literals (one per lane group) */
+    uint64_t bcp_steps;        /* BCP steps; each propagates up to 32 queue literals (one per lane group) */
     uint64_t bcp_requeued;     /* literals re-queued because two groups met in one clause */
     uint64_t shared_exported;  /* clauses workers offered to the exchange / clauses (and units) attached from it, */
     uint64_t shared_imported;  /* summed over workers */
