@@ -620,3 +620,101 @@ def test_emulated_lookahead_loop_is_the_sequential_loop(terrain, pset, k0, kstar
     assert sat and sat[-1]["count"] == kstar and all(h["valid"] and h["count"] <= h["k"] for h in sat)
     assert lines[-1] == "No solution found for the current constraints"
     assert f"Solution found ({kstar} platforms total)" in lines and "Solution validation FAILED" not in lines
+
+
+def _long_list_formula(seed, n_vars=360, n_long=140, n_hubs=6, per_hub=44, hub_len=(9, 40)):
+    """A formula cut for the BCP step's side paths: clauses of 10..48 literals (tails to scan, several per step), a few
+    hub literals watched by 44 long clauses each (watch lists far longer than a lane group: the flat remainder, its
+    in-place compaction and the re-queueing when two groups meet in one clause), binary and ternary chains between."""
+    rng = np.random.default_rng(seed)
+    clauses = []
+
+    def rand_clause(k, first=None):
+        vs = rng.choice(np.arange(n_hubs, n_vars), size=k, replace=False)
+        c = [int(v + 1) * (1 if rng.random() < 0.5 else -1) for v in vs]
+        return ([first] + c) if first is not None else c
+
+    for _ in range(n_long):
+        clauses.append(rand_clause(int(rng.integers(10, 49))))
+    for h in range(n_hubs):                          # -(h+1) in a watched position of every one of its clauses
+        for _ in range(per_hub):
+            c = rand_clause(int(rng.integers(hub_len[0], hub_len[1])), first=-(h + 1))
+            if rng.random() < 0.5:
+                c[0], c[1] = c[1], c[0]
+            clauses.append(c)
+    for _ in range(n_vars):                          # implication chains
+        a, b, c = (int(x) for x in rng.choice(np.arange(n_hubs, n_vars), size=3, replace=False))
+        sa, sb, sc = (1 if rng.random() < 0.5 else -1 for _ in range(3))
+        clauses.append([sa * (a + 1), sb * (b + 1)] if rng.random() < 0.35 else [sa * (a + 1), sb * (b + 1), sc * (c + 1)])
+    lits = np.array([l for c in clauses for l in c], dtype=np.int32)
+    offsets = np.cumsum([0] + [len(c) for c in clauses]).astype(np.uint64)
+    return lits, offsets, n_vars, n_hubs, rng
+
+
+@pytest.mark.parametrize("lds_val", [0, -1], ids=["assignment-in-lds", "assignment-in-slab"])
+def test_emulated_bcp_fixpoints_long_clauses_and_long_watch_lists(lds_val):
+    """propagate() against the oracle's occurrence-list BCP on formulas whose steps take every side path: several
+    clause tails per step, watch lists of 44 long clauses (remainder spread flat over the wave), moved watches, two
+    groups meeting in one clause.  Fixpoints are unique, so they must agree literal for literal (and so must "conflict")."""
+    n_fix = n_conf = 0
+    for seed in (11, 12, 13):
+        lits, offsets, n_vars, n_hubs, rng = _long_list_formula(seed)
+        scripts = []
+        for _ in range(10):
+            dec = [int(h + 1) for h in rng.permutation(n_hubs)[: int(rng.integers(1, n_hubs + 1))]]
+            dec += [int(v + 1) * (1 if rng.random() < 0.5 else -1) for v in rng.choice(np.arange(n_hubs, n_vars), size=int(rng.integers(4, 110)), replace=False)]
+            scripts.append([int(x) for x in rng.permutation(dec)])
+        s = emu_solver(lds_val=lds_val, simp=-1)
+        s.add_cnf(lits, offsets)
+        confl, vals, tl = s.propagate_batch(scripts, n_vars=n_vars)
+        for i, dec in enumerate(scripts):
+            c, v, n, _ = ora.bcp(lits, offsets, n_vars, dec)
+            assert c == confl[i], (seed, i)
+            if c:
+                n_conf += 1
+            else:
+                n_fix += 1
+                assert np.array_equal(v, vals[i]) and n == tl[i], (seed, i)
+        st = s.stats()
+        assert st["n_move"] > 0 and st["n_cl_lit"] > 8 * st["n_move"]       # watches moved, tails scanned
+        s.close()
+    assert n_fix >= 5 and n_conf >= 3
+
+
+@pytest.mark.parametrize("lds_val", [0, -1], ids=["assignment-in-lds", "assignment-in-slab"])
+def test_emulated_search_keeps_long_watch_lists_intact(lds_val):
+    """The same side paths under SEARCH: lists are revisited after backjumps and rewritten in place by the flat remainder,
+    learnt clauses of tens of literals join them.  Verdicts against the oracle, models against every clause.  (What this
+    cannot see: ONE watcher of a clause lost - the other watch still finds the conflict, only later; tried by mutation.)
+    A random 3-SAT core (120 variables, 3.0 clauses per variable on top of the chains) keeps the conflicts coming; the
+    hubs (40 clauses of 4..6 literals each, tight enough to propagate) and the long clauses sit on its variables."""
+    n_sat = n_unsat = 0
+    for seed in (21, 22, 25, 26):
+        # (hub clauses of 4..6 literals: tight enough that a watcher lost from a hub's list costs a propagation)
+        lits, offsets, n_vars, n_hubs, rng = _long_list_formula(seed, n_vars=240, n_long=90, per_hub=40, hub_len=(3, 6))
+        core = np.arange(n_hubs, n_hubs + 120)
+        extra = []
+        for _ in range(int(3.0 * 120)):
+            vs = rng.choice(core, size=3, replace=False)
+            extra.append([int(v + 1) * (1 if rng.random() < 0.5 else -1) for v in vs])
+        for h in range(n_hubs):                       # the hubs are implied now and then: core literal -> hub
+            for _ in range(3):
+                extra.append([-int(rng.choice(core) + 1), h + 1])
+        lits = np.concatenate([lits, np.array([l for c in extra for l in c], dtype=np.int32)])
+        offsets = np.concatenate([offsets, offsets[-1] + np.cumsum([len(c) for c in extra]).astype(np.uint64)])
+        o = ora.OracleSolver()
+        o.add_cnf(lits, offsets)
+        want = o.solve()
+        s = emu_solver(workers=2, slice_conflicts=400, reduce_first=60, reduce_inc=20, lds_val=lds_val, simp=-1)
+        s.add_cnf(lits, offsets)
+        r = s.solve()
+        assert (r == SolverResult.Sat) == (want == 10) and r in (SolverResult.Sat, SolverResult.Unsat), (seed, r, want)
+        if r == SolverResult.Sat:
+            n_sat += 1
+            assert ora.check_model(lits, offsets, s.full_solution(n_vars)) == -1
+        else:
+            n_unsat += 1
+        st = s.stats()
+        assert st["conflicts"] >= 20 and st["n_move"] > 1000, (seed, st["conflicts"], st["n_move"])
+        s.close()
+    assert n_sat >= 1 and n_unsat >= 1, (n_sat, n_unsat)
