@@ -127,3 +127,32 @@ def assert_ring_records_are_implied(solver, cnf, max_records=None):
         seen.add(key)
         assert o.solve([-l for l in c]) == 20, ("exchange ring holds a clause the formula does not imply", c)
     return len(recs)
+
+
+def long_list_formula(seed, n_vars=360, n_long=140, n_hubs=6, per_hub=44, hub_len=(9, 40)):
+    """A formula cut for the BCP step's side paths: clauses of 10..48 literals (tails to scan, several per step), a few
+    hub literals watched by 44 long clauses each (watch lists far longer than a lane group: the flat remainder, its
+    in-place compaction and the re-queueing when two groups meet in one clause), binary and ternary chains between."""
+    rng = np.random.default_rng(seed)
+    clauses = []
+
+    def rand_clause(k, first=None):
+        vs = rng.choice(np.arange(n_hubs, n_vars), size=k, replace=False)
+        c = [int(v + 1) * (1 if rng.random() < 0.5 else -1) for v in vs]
+        return ([first] + c) if first is not None else c
+
+    for _ in range(n_long):
+        clauses.append(rand_clause(int(rng.integers(10, 49))))
+    for h in range(n_hubs):                          # -(h+1) in a watched position of every one of its clauses
+        for _ in range(per_hub):
+            c = rand_clause(int(rng.integers(hub_len[0], hub_len[1])), first=-(h + 1))
+            if rng.random() < 0.5:
+                c[0], c[1] = c[1], c[0]
+            clauses.append(c)
+    for _ in range(n_vars):                          # implication chains
+        a, b, c = (int(x) for x in rng.choice(np.arange(n_hubs, n_vars), size=3, replace=False))
+        sa, sb, sc = (1 if rng.random() < 0.5 else -1 for _ in range(3))
+        clauses.append([sa * (a + 1), sb * (b + 1)] if rng.random() < 0.35 else [sa * (a + 1), sb * (b + 1), sc * (c + 1)])
+    lits = np.array([l for c in clauses for l in c], dtype=np.int32)
+    offsets = np.cumsum([0] + [len(c) for c in clauses]).astype(np.uint64)
+    return lits, offsets, n_vars, n_hubs, rng

@@ -8,7 +8,8 @@ import time
 import numpy as np
 import pytest
 
-from helpers import assert_ring_records_are_implied, VERDICTS, check_sat_answer, emu_lib, make_grid, platform_defs, scripted_decisions
+from helpers import (assert_ring_records_are_implied, VERDICTS, check_sat_answer, emu_lib, long_list_formula, make_grid, platform_defs,
+                     scripted_decisions)
 from oracle import oracle as ora
 from timberborn_support_solver_amd import Encoding, Mi355Sat, PlatformLimits, SolverResult, solver_loop
 
@@ -622,35 +623,6 @@ def test_emulated_lookahead_loop_is_the_sequential_loop(terrain, pset, k0, kstar
     assert f"Solution found ({kstar} platforms total)" in lines and "Solution validation FAILED" not in lines
 
 
-def _long_list_formula(seed, n_vars=360, n_long=140, n_hubs=6, per_hub=44, hub_len=(9, 40)):
-    """A formula cut for the BCP step's side paths: clauses of 10..48 literals (tails to scan, several per step), a few
-    hub literals watched by 44 long clauses each (watch lists far longer than a lane group: the flat remainder, its
-    in-place compaction and the re-queueing when two groups meet in one clause), binary and ternary chains between."""
-    rng = np.random.default_rng(seed)
-    clauses = []
-
-    def rand_clause(k, first=None):
-        vs = rng.choice(np.arange(n_hubs, n_vars), size=k, replace=False)
-        c = [int(v + 1) * (1 if rng.random() < 0.5 else -1) for v in vs]
-        return ([first] + c) if first is not None else c
-
-    for _ in range(n_long):
-        clauses.append(rand_clause(int(rng.integers(10, 49))))
-    for h in range(n_hubs):                          # -(h+1) in a watched position of every one of its clauses
-        for _ in range(per_hub):
-            c = rand_clause(int(rng.integers(hub_len[0], hub_len[1])), first=-(h + 1))
-            if rng.random() < 0.5:
-                c[0], c[1] = c[1], c[0]
-            clauses.append(c)
-    for _ in range(n_vars):                          # implication chains
-        a, b, c = (int(x) for x in rng.choice(np.arange(n_hubs, n_vars), size=3, replace=False))
-        sa, sb, sc = (1 if rng.random() < 0.5 else -1 for _ in range(3))
-        clauses.append([sa * (a + 1), sb * (b + 1)] if rng.random() < 0.35 else [sa * (a + 1), sb * (b + 1), sc * (c + 1)])
-    lits = np.array([l for c in clauses for l in c], dtype=np.int32)
-    offsets = np.cumsum([0] + [len(c) for c in clauses]).astype(np.uint64)
-    return lits, offsets, n_vars, n_hubs, rng
-
-
 @pytest.mark.parametrize("lds_val", [0, -1], ids=["assignment-in-lds", "assignment-in-slab"])
 def test_emulated_bcp_fixpoints_long_clauses_and_long_watch_lists(lds_val):
     """propagate() against the oracle's occurrence-list BCP on formulas whose steps take every side path: several
@@ -658,7 +630,7 @@ def test_emulated_bcp_fixpoints_long_clauses_and_long_watch_lists(lds_val):
     groups meeting in one clause.  Fixpoints are unique, so they must agree literal for literal (and so must "conflict")."""
     n_fix = n_conf = 0
     for seed in (11, 12, 13):
-        lits, offsets, n_vars, n_hubs, rng = _long_list_formula(seed)
+        lits, offsets, n_vars, n_hubs, rng = long_list_formula(seed)
         scripts = []
         for _ in range(10):
             dec = [int(h + 1) for h in rng.permutation(n_hubs)[: int(rng.integers(1, n_hubs + 1))]]
@@ -691,7 +663,7 @@ def test_emulated_search_keeps_long_watch_lists_intact(lds_val):
     n_sat = n_unsat = 0
     for seed in (21, 22, 25, 26):
         # (hub clauses of 4..6 literals: tight enough that a watcher lost from a hub's list costs a propagation)
-        lits, offsets, n_vars, n_hubs, rng = _long_list_formula(seed, n_vars=240, n_long=90, per_hub=40, hub_len=(3, 6))
+        lits, offsets, n_vars, n_hubs, rng = long_list_formula(seed, n_vars=240, n_long=90, per_hub=40, hub_len=(3, 6))
         core = np.arange(n_hubs, n_hubs + 120)
         extra = []
         for _ in range(int(3.0 * 120)):

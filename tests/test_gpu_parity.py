@@ -8,7 +8,7 @@ import time
 import numpy as np
 import pytest
 
-from helpers import VERDICTS, check_sat_answer, make_grid, platform_defs, scripted_decisions
+from helpers import VERDICTS, check_sat_answer, long_list_formula, make_grid, platform_defs, scripted_decisions
 from oracle import oracle as ora
 from timberborn_support_solver_amd import (Encoding, Mi355Sat, PlatformLayout, PlatformLimits, SolverResult,
                                            algorithmic_bytes, solver_loop)
@@ -527,3 +527,61 @@ def test_deterministic_mode_repeats_itself_on_the_gpu():
         s.close()
     assert runs[0] == runs[1], runs
     assert runs[0][0] > 0 and runs[0][4] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lds_val", [0, -1], ids=["assignment-in-lds", "assignment-in-slab"])
+def test_bcp_fixpoints_long_clauses_and_long_watch_lists(lds_val):
+    """propagate() on the MI355X against the oracle's occurrence-list BCP on formulas cut for the step's side paths
+    (tests/helpers.py::long_list_formula: several clause tails per step, watch lists of 44 long clauses spread flat over the
+    wave, moved watches, two groups meeting in one clause) - the emulator runs the same in tests/test_emu_kernels.py."""
+    n_fix = n_conf = 0
+    for seed in (11, 12, 13, 14):
+        lits, offsets, n_vars, n_hubs, rng = long_list_formula(seed)
+        scripts = []
+        for _ in range(24):
+            dec = [int(h + 1) for h in rng.permutation(n_hubs)[: int(rng.integers(1, n_hubs + 1))]]
+            dec += [int(v + 1) * (1 if rng.random() < 0.5 else -1) for v in rng.choice(np.arange(n_hubs, n_vars), size=int(rng.integers(4, 110)), replace=False)]
+            scripts.append([int(x) for x in rng.permutation(dec)])
+        s = Mi355Sat(lds_val=lds_val, simp=-1)
+        s.add_cnf(lits, offsets)
+        confl, vals, tl = s.propagate_batch(scripts, n_vars=n_vars)
+        for i, dec in enumerate(scripts):
+            c, v, n, _ = ora.bcp(lits, offsets, n_vars, dec)
+            assert c == confl[i], (seed, i)
+            if c:
+                n_conf += 1
+            else:
+                n_fix += 1
+                assert np.array_equal(v, vals[i]) and n == tl[i], (seed, i)
+        s.close()
+    assert n_fix >= 10 and n_conf >= 5
+
+
+@pytest.mark.gpu
+def test_search_on_long_watch_lists_agrees_with_the_oracle():
+    """CDCL on the same kind of formula (tight hub clauses, a random 3-SAT core): verdict = the oracle's, models satisfy
+    every clause.  Default fleet, default options."""
+    for seed in (21, 22, 25, 26):
+        lits, offsets, n_vars, n_hubs, rng = long_list_formula(seed, n_vars=240, n_long=90, per_hub=40, hub_len=(3, 6))
+        core = np.arange(n_hubs, n_hubs + 120)
+        extra = []
+        for _ in range(int(3.0 * 120)):
+            vs = rng.choice(core, size=3, replace=False)
+            extra.append([int(v + 1) * (1 if rng.random() < 0.5 else -1) for v in vs])
+        for h in range(n_hubs):
+            for _ in range(3):
+                extra.append([-int(rng.choice(core) + 1), h + 1])
+        lits = np.concatenate([lits, np.array([l for c in extra for l in c], dtype=np.int32)])
+        offsets = np.concatenate([offsets, offsets[-1] + np.cumsum([len(c) for c in extra]).astype(np.uint64)])
+        o = ora.OracleSolver()
+        o.add_cnf(lits, offsets)
+        want = o.solve()
+        s = Mi355Sat()
+        s.add_cnf(lits, offsets)
+        r = s.solve()
+        assert (r == SolverResult.Sat) == (want == 10) and r in (SolverResult.Sat, SolverResult.Unsat), (seed, r, want)
+        if r == SolverResult.Sat:
+            assert ora.check_model(lits, offsets, s.full_solution(n_vars)) == -1
+        s.close()
+
