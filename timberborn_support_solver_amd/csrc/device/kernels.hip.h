@@ -62,6 +62,9 @@ enum { PF_OFF = 0, PF_BIN, PF_TERN, PF_LONG, PF_CLOSE, PF_ANALYZE, PF_BACKJUMP, 
        PF_RES_STEPS = PF_N, PF_MIN_DEEP, PF_MIN_LOCAL, PF_MIN_NODES, PF_MIN_CALLS, PF_ALL };
 
 #define DEV __device__ __forceinline__
+#ifndef MS_BATCH_WALK
+#define MS_BATCH_WALK 1     // batched resolution also where the analysis marks are bytes in the variable records (0: one literal per round)
+#endif
 #ifndef MS_TAIL_UNROLL
 #define MS_TAIL_UNROLL 2      // chunks of a clause tail examined per round trip (long_eval, phase B)
 #endif
@@ -1179,10 +1182,19 @@ DEV void analyze_visit(Wk& w, const MsShared& sh, const MsLayout& L, Gp<MsVarRec
             else fresh = !(w.lseen[v >> 5] & bit) && !(w.lzero[v >> 5] & bit);
             cur = fresh && (w.lcur[v >> 5] & bit);
         }
-    } else if (act) {
-        const MsVarRec vr = vrec[v];
-        fresh = !vr.seen && vr.level > 0;
-        cur = fresh && vr.level >= dl;
+    } else {
+        bool atdl = false;
+        if (act) {
+            const MsVarRec vr = vrec[v];
+            fresh = !vr.seen && vr.level > 0;
+            atdl = vr.level >= dl;
+        }
+        if (CLAIM) {    // the marks are bytes in the records here: an exact claim set (the one BCP's commit uses) keeps one of the lanes that present the same variable
+            claims_clear(w);
+            fresh = claim_insert(w, fresh, q) == CLAIM_WON;
+            lds_fence();
+        }
+        cur = fresh && atdl;
     }
     u64 fm = ballot(fresh), cm = ballot(cur);
     u64 lm = fm & ~cm;
@@ -1218,7 +1230,7 @@ DEV void analyze_visit_clause(Wk& w, const MsShared& sh, const MsLayout& L, Gp<M
 // (the last open one is the UIP and must not be resolved).  Round 2 resolved one literal per iteration (~160 per
 // conflict at ~1 us each).  Returns the UIP literal, or -1 (internal error).
 template <bool LV>
-DEV int analyze_walk_lds(Wk& w, const MsShared& sh, const MsLayout& L, Gp<MsVarRec> vrec, Gp<int32_t> toclear, Gp<int32_t> learnt_buf,
+DEV int analyze_walk(Wk& w, const MsShared& sh, const MsLayout& L, Gp<MsVarRec> vrec, Gp<int32_t> toclear, Gp<int32_t> learnt_buf,
                          Gp<uint32_t> lc_lbd, int dl, int& path_c, int& n_out, int& n_clear) {
     int index = w.trail_n - 1;
     for (;;) {
@@ -1232,12 +1244,19 @@ DEV int analyze_walk_lds(Wk& w, const MsShared& sh, const MsLayout& L, Gp<MsVarR
         int4 l0 = make_int4(0, 0, 0, 0), l1 = make_int4(0, 0, 0, 0);
         for (;;) {
             lds_fence();
-            const bool mine = pos >= 0 && pos <= index && ((w.lseen[myv >> 5] >> (myv & 31)) & 1u);
+            bool mine;
+            if (LV) mine = pos >= 0 && pos <= index && ((w.lseen[myv >> 5] >> (myv & 31)) & 1u);
+            else {      // marks in the records: every lane of the chunk still in play re-reads its own (one round trip per round)
+                wave_fence();
+                const bool inr = pos >= 0 && pos <= index;
+                if (inr) rec = vrec[myv];
+                mine = inr && rec.seen;
+            }
             const u64 sm = ballot(mine);
             if (sm == 0) break;
             const int cnt = popc64(sm);
             if (mine && !have) {    // records, then reason heads, of every marked literal of the chunk not fetched yet
-                rec = vrec[myv];
+                if (LV) rec = vrec[myv];
                 const int rr = rec.reason;
                 if (rr >= 0 && rec.size > 0) {
                     Gp<const int32_t> cl = lits_base(w, sh, L, rr) + rec.start;
@@ -1261,8 +1280,9 @@ DEV int analyze_walk_lds(Wk& w, const MsShared& sh, const MsLayout& L, Gp<MsVarR
                 index = chunk_hi - f - 1;
                 path_c--;
                 if (path_c <= 0) {      // the first UIP: not resolved
-                    if (me) lds_and(&w.lseen[myv >> 5], ~(1u << (myv & 31)));
+                    if (me) seen_clr<LV>(w, sh, L, myv);
                     lds_fence();
+                    wave_fence();
                     return bcast(my, f);
                 }
             }
@@ -1297,7 +1317,8 @@ DEV int analyze_walk_lds(Wk& w, const MsShared& sh, const MsLayout& L, Gp<MsVarR
             }
             // the resolved literals' own marks go LAST: while they stand, no reason of this round can mark them anew
             lds_fence();
-            if (me) lds_and(&w.lseen[myv >> 5], ~(1u << (myv & 31)));
+            wave_fence();
+            if (me) seen_clr<LV>(w, sh, L, myv);
         }
         index = chunk_hi - MS_WAVE;     // nothing marked is left in this chunk at or below `index`
     }
@@ -1310,22 +1331,12 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
     Gp<int32_t> learnt_buf = WK_PTR(int32_t, w, L, learnt_buf);
     Gp<uint32_t> lc_lbd = WK_PTR(uint32_t, w, L, lc_lbd);
     int path_c = 0, p = -1, n_out = 1, n_clear = 0;
-    int index = w.trail_n - 1;
-    int chunk_hi = -1, chunk_l = 0;   // cached chunk of the trail (LV)
-    // (LV) per lane: the variable record of the lane's trail literal and the head of its reason - for a long reason its
-    // first 8 literals, for a ternary one the clause - fetched for ALL marked literals of the chunk at once (two round
-    // trips for the lot) and kept in registers: most resolution steps then touch no memory at all
-    MsVarRec c_rec = MsVarRec{0, MS_REASON_NONE, 0, 0, 0, 0};
-    int4 c_l0 = make_int4(0, 0, 0, 0), c_l1 = make_int4(0, 0, 0, 0);
-    bool c_ok = false;
-    int4 pre0 = make_int4(0, 0, 0, 0), pre1 = make_int4(0, 0, 0, 0);   // uniform: head of the clause about to be visited
-    int pre_n = 0;
     const int dl = w.n_levels;
     int kind = w.confl_kind, cref = w.confl_cref, ba = w.confl_a, bb = w.confl_b, bc = w.confl_c;
-    if (LV) {       // the conflict clause, then the batched walk (analyze_walk_lds)
+    if (LV || MS_BATCH_WALK) {       // the conflict clause, then the batched walk (analyze_walk)
         if (kind == 1) {
             Gp<const int32_t> cl;
-            int size = bc;
+            int size = bc;     // kind 1: (bb, bc) = the clause's literal range when known (size 0: look it up)
             if (size > 0) cl = lits_base(w, sh, L, cref) + (uint32_t)bb;
             else clause_range(w, sh, L, cref, cl, size);
             if ((uint32_t)cref >= sh.n_orig && w.lane == 0) lc_lbd[cref - sh.n_orig] |= 0x80000000u;  // used
@@ -1334,61 +1345,33 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
             const int q = w.lane == 0 ? ba : (w.lane == 1 ? bb : bc);
             analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, w.lane < kind, q, dl, path_c, n_out, n_clear);
         }
-        p = analyze_walk_lds<LV>(w, sh, L, vrec, toclear, learnt_buf, lc_lbd, dl, path_c, n_out, n_clear);
+        p = analyze_walk<LV>(w, sh, L, vrec, toclear, learnt_buf, lc_lbd, dl, path_c, n_out, n_clear);
         if (p < 0) return Learnt{0, 0, 0};
-    } else
-    for (;;) {
-        if (kind == 1) {
-            Gp<const int32_t> cl;
-            int size = bc;     // kind 1: (bb, bc) = the clause's literal range when known (size 0: look it up)
-            if (size > 0) cl = lits_base(w, sh, L, cref) + (uint32_t)bb;
-            else clause_range(w, sh, L, cref, cl, size);
-            if ((uint32_t)cref >= sh.n_orig && w.lane == 0) lc_lbd[cref - sh.n_orig] |= 0x80000000u;  // used
-            for (int k0 = 0; k0 < size; k0 += MS_WAVE) {
-                int k = k0 + w.lane;
-                int q = 0;
-                if (k < pre_n) {   // the first literals came with the prefetch of the reason (uniform values, lane k takes the k-th)
-                    q = k < 4 ? (k < 2 ? (k == 0 ? pre0.x : pre0.y) : (k == 2 ? pre0.z : pre0.w))
-                              : (k < 6 ? (k == 4 ? pre1.x : pre1.y) : (k == 6 ? pre1.z : pre1.w));
-                } else if (k < size) q = cl[k];
-                analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, k < size && q != p, q, dl, path_c, n_out, n_clear);
-            }
-            pre_n = 0;
-        } else {
-            int q = w.lane == 0 ? ba : (w.lane == 1 ? bb : bc);
-            analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, w.lane < kind && q != p, q, dl, path_c, n_out, n_clear);
-        }
-        wave_fence();
-        if (LV) {
-            // walk the trail back to the most recent literal marked seen.  The marks are in LDS, so a chunk of 64
-            // trail entries (one coalesced load, lane i holds position chunk_hi - i) is tested at once and is kept
-            // in registers across resolution steps until the walk leaves it.
-            lds_fence();
-            for (;;) {
-                if (chunk_hi < 0 || index > chunk_hi || index <= chunk_hi - MS_WAVE) {
-                    chunk_hi = index;
-                    const int i = chunk_hi - w.lane;
-                    chunk_l = i >= 0 ? WKA(int32_t, trail)[i] : 0;
-                    c_ok = false;
+    } else {
+        // MS_BATCH_WALK = 0 (A/B reference, marks in the records): one literal resolved per iteration - its reason's
+        // literals visited, then the trail walked back to the next marked literal.  A chunk of 64 trail entries stays in
+        // registers across iterations (lane i holds position chunk_hi - i); the 16 positions below `index` are tested first
+        // (each costs a random record line and the next marked literal is usually close), the rest of the chunk only when
+        // those miss.  The lane that finds p has loaded p's whole record - its reason and where the reason's literals are.
+        int index = w.trail_n - 1, chunk_hi = -1, chunk_l = 0;
+        MsVarRec c_rec = MsVarRec{0, MS_REASON_NONE, 0, 0, 0, 0};
+        for (;;) {
+            if (kind == 1) {
+                Gp<const int32_t> cl;
+                int size = bc;
+                if (size > 0) cl = lits_base(w, sh, L, cref) + (uint32_t)bb;
+                else clause_range(w, sh, L, cref, cl, size);
+                if ((uint32_t)cref >= sh.n_orig && w.lane == 0) lc_lbd[cref - sh.n_orig] |= 0x80000000u;  // used
+                for (int k0 = 0; k0 < size; k0 += MS_WAVE) {
+                    const int k = k0 + w.lane;
+                    const int q = k < size ? cl[k] : 0;
+                    analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, k < size && q != p, q, dl, path_c, n_out, n_clear);
                 }
-                const int pos = chunk_hi - w.lane;
-                const bool ok = pos >= 0 && pos <= index && seen_get<LV>(w, sh, L, chunk_l >> 1);
-                const u64 m = ballot(ok);
-                if (m) {
-                    const int f = first_lane(m);
-                    index = chunk_hi - f;
-                    p = bcast(chunk_l, f);
-                    break;
-                }
-                index = chunk_hi - MS_WAVE;
-                if (index < 0) { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
+            } else {
+                const int q = w.lane == 0 ? ba : (w.lane == 1 ? bb : bc);
+                analyze_visit<LV>(w, sh, L, vrec, toclear, learnt_buf, w.lane < kind && q != p, q, dl, path_c, n_out, n_clear);
             }
-        } else {
-            // The marks are bytes in the variable records here.  A chunk of 64 trail entries stays in registers across
-            // resolution steps (lane i holds position chunk_hi - i); the 16 positions below `index` are tested first
-            // (each costs a random record line and the next marked literal is usually close), the rest of the chunk
-            // only when those miss.  The lane that finds p has loaded p's whole record - its reason and where the
-            // reason's literals are - so the step needs no round trip of its own for that.
+            wave_fence();
             bool wide = false;
             for (;;) {
                 if (chunk_hi < 0 || index > chunk_hi || index <= chunk_hi - MS_WAVE) {
@@ -1411,66 +1394,27 @@ DEV Learnt analyze(Wk& w, const MsShared& sh, const MsLayout& L, uint32_t stamp)
                 index = chunk_hi - MS_WAVE;
                 if (index < 0) { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
             }
-        }
-        index--;
+            index--;
 #ifdef MS_PROFILE
-        w.prof[PF_N]++;                    // resolution steps (diagnostic build)
+            w.prof[PF_N]++;                    // resolution steps (diagnostic build)
 #endif
-        const int v = p >> 1;
-        if (LV) {
-            const int f = chunk_hi - (index + 1);      // the lane that holds p
-            if (!bcast((int)c_ok, f)) {
-                // fetch for every marked literal of the chunk that is still to come (p included): records, then reason heads
-                const int pos = chunk_hi - w.lane;
-                const bool want = !c_ok && pos >= 0 && pos <= index + 1 && seen_get<LV>(w, sh, L, chunk_l >> 1);
-                if (want) c_rec = VREC[chunk_l >> 1];
-                if (want) {
-                    const int rr = c_rec.reason;
-                    if (rr >= 0 && c_rec.size > 0) {
-                        Gp<const int32_t> cl = lits_base(w, sh, L, rr) + c_rec.start;
-                        c_l0 = *(Gp<const int4>)cl;
-                        if (c_rec.size > 4) c_l1 = *(Gp<const int4>)(cl + 4);
-                    } else if (rr < 0 && MS_IS_TERN_REASON(rr)) {
-                        const int e = MS_TERN_REASON_ENTRY(rr);
-                        const int2 tp = ((Gp<const int2>)sh.tern_pairs)[e];
-                        c_l0 = make_int4(((Gp<const int32_t>)sh.tern_owner)[e] ^ 1, tp.x, tp.y, 0);
-                    }
-                    c_ok = true;
-                }
-            }
-            const int r = bcast(c_rec.reason, f);
+            const int v = p >> 1;
+            const int fp = chunk_hi - (index + 1);      // the lane that holds p and its record
+            const int r = bcast(c_rec.reason, fp);
             wave_fence();
             if (w.lane == 0) seen_clr<LV>(w, sh, L, v);
             lds_fence();
             path_c--;
             if (path_c <= 0) break;
-            if (r >= 0) {
-                kind = 1; cref = r; bb = bcast((int)c_rec.start, f); bc = bcast((int)c_rec.size, f);
-                if (bc > 0) {
-                    pre0 = make_int4(bcast(c_l0.x, f), bcast(c_l0.y, f), bcast(c_l0.z, f), bcast(c_l0.w, f));
-                    pre1 = make_int4(bcast(c_l1.x, f), bcast(c_l1.y, f), bcast(c_l1.z, f), bcast(c_l1.w, f));
-                    pre_n = bc < 8 ? bc : 8;
-                }
-            } else if (MS_IS_TERN_REASON(r)) { kind = 3; ba = bcast(c_l0.x, f); bb = bcast(c_l0.y, f); bc = bcast(c_l0.z, f); }
+            if (r >= 0) { kind = 1; cref = r; bb = bcast((int)c_rec.start, fp); bc = bcast((int)c_rec.size, fp); }
+            else if (MS_IS_TERN_REASON(r)) {
+                const int e = MS_TERN_REASON_ENTRY(r);
+                const int2 pr = ((Gp<const int2>)sh.tern_pairs)[e];
+                kind = 3; ba = uni(((Gp<const int32_t>)sh.tern_owner)[e]) ^ 1; bb = uni(pr.x); bc = uni(pr.y);
+            }
             else if (MS_IS_BIN_REASON(r)) { kind = 2; ba = p; bb = MS_BIN_REASON_LIT(r); }
             else { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
-            continue;
         }
-        const int fp = chunk_hi - (index + 1);      // the lane that holds p and its record
-        const int r = bcast(c_rec.reason, fp);
-        wave_fence();
-        if (w.lane == 0) seen_clr<LV>(w, sh, L, v);
-        lds_fence();
-        path_c--;
-        if (path_c <= 0) break;
-        if (r >= 0) { kind = 1; cref = r; bb = bcast((int)c_rec.start, fp); bc = bcast((int)c_rec.size, fp); }
-        else if (MS_IS_TERN_REASON(r)) {
-            const int e = MS_TERN_REASON_ENTRY(r);
-            const int2 pr = ((Gp<const int2>)sh.tern_pairs)[e];
-            kind = 3; ba = uni(((Gp<const int32_t>)sh.tern_owner)[e]) ^ 1; bb = uni(pr.x); bc = uni(pr.y);
-        }
-        else if (MS_IS_BIN_REASON(r)) { kind = 2; ba = p; bb = MS_BIN_REASON_LIT(r); }
-        else { w.status = MS_ST_ERR_INTERNAL; return Learnt{0, 0, 0}; }
     }
     wave_fence();
     if (w.lane == 0) learnt_buf[0] = p ^ 1;
