@@ -14,7 +14,8 @@ sizes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [16, 
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 limit = float(sys.argv[3]) if len(sys.argv) > 3 else 150
 cpu_limit = float(sys.argv[4]) if len(sys.argv) > 4 else 240
-lookahead = bool(int(os.environ.get("LOOKAHEAD", "0")))     # the last bounds two at a time (loop.py::solver_loop_pair)
+_la = int(os.environ.get("LOOKAHEAD", "0"))     # 1: the last bounds two at a time (loop.py::solver_loop_pair); N >= 3: N at a time (solver_loop_fan)
+lookahead = False if _la == 0 else (True if _la <= 2 else _la)
 KW = dict(kv.split("=") for kv in os.environ.get("SOLVER_OPTS", "").split(",") if kv)
 KW = {k: int(v) for k, v in KW.items()}
 for m in sizes:

@@ -623,6 +623,30 @@ def test_emulated_lookahead_loop_is_the_sequential_loop(terrain, pset, k0, kstar
     assert f"Solution found ({kstar} platforms total)" in lines and "Solution validation FAILED" not in lines
 
 
+@pytest.mark.parametrize("terrain,pset,k0,kstar,width", [("ex1", "1x1", 6, 3, 3), ("rect8x8", "1x1", 8, 4, 4), ("rect8x8", "default", 5, 2, 4)])
+def test_emulated_fan_loop_is_the_sequential_loop(terrain, pset, k0, kstar, width):
+    """solver_loop_fan: `width` bounds side by side (one handle, one host thread each); what comes out is the reference's
+    loop - its messages, valid layouts with count <= the bound posed, the golden optimum and the refuted bound - and no
+    solver is left running."""
+    from timberborn_support_solver_amd import solver_loop_fan
+    grid = make_grid(terrain)
+    enc = Encoding.encode(platform_defs(pset), grid)
+    lines, made = [], []
+
+    def mk():
+        made.append(emu_solver(workers=2, slice_conflicts=20))
+        return made[-1]
+
+    hist = solver_loop_fan(grid, enc, PlatformLimits({(1, 1): k0}), out=lines.append, make_solver=mk, width=width)
+    assert hist[-1]["result"] == SolverResult.Unsat and hist[-1]["k"] == kstar - 1
+    sat = [h for h in hist if h["result"] == SolverResult.Sat]
+    assert sat and sat[-1]["count"] == kstar and all(h["valid"] and h["count"] <= h["k"] for h in sat)
+    assert [h["k"] for h in hist] == sorted((h["k"] for h in hist), reverse=True)
+    assert lines[-1] == "No solution found for the current constraints"
+    assert f"Solution found ({kstar} platforms total)" in lines and "Solution validation FAILED" not in lines
+    assert len(made) >= width and all(m._h is None or not m._h for m in made)      # every handle closed
+
+
 @pytest.mark.parametrize("lds_val", [0, -1], ids=["assignment-in-lds", "assignment-in-slab"])
 def test_emulated_bcp_fixpoints_long_clauses_and_long_watch_lists(lds_val):
     """propagate() against the oracle's occurrence-list BCP on formulas whose steps take every side path: several

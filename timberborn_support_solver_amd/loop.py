@@ -177,6 +177,124 @@ def solver_loop_pair(grid, encoding, limits, make_solver=None, out=print, on_int
             a, b = start(nxt), (start(nxt - 1) if nxt >= 1 else None)
 
 
+def solver_loop_fan(grid, encoding, limits, make_solver=None, out=print, on_interrupter=None, width=4):
+    """The reference's sequential loop (main.rs:290-346) with `width - 1` bounds of lookahead: the bound k the reference
+    would pose next and the bounds k - 1 ... k - width + 1 run side by side, each in a solver of its own (its own CNF
+    as the reference makes it, its own stream and host thread, 1 / width of the default fleet: a quarter of it decides a
+    hard bound at two thirds of the whole fleet's speed, profiles/r03_m_knob_sweep1.log).  Near the optimum a ladder
+    spends as long on its last few models as on the refutation (rect 32x32: 2 + 2 + 5 + 10 s of models, 13 s of
+    refutation): this way they overlap.  What the caller sees is the reference's loop - its messages in its order, one
+    record per improvement and the refuting bound:
+      any bound b SAT with count c   -> every bound >= c is answered: their solves are dropped, the model is the
+                                        iteration's (for the bound the reference would have posed), next bound c - 1
+      any bound b UNSAT              -> every bound <= b is refuted: their solves are dropped; if b is the bound the
+                                        reference would pose now the loop ends, else it ends as soon as a model's
+                                        count - 1 reaches a refuted bound"""
+    import threading
+    front = limits.card_limits[(1, 1)]
+    history, jobs, refuted = [], {}, {"k": -1, "seconds": 0.0}
+
+    def make(cnf):
+        if make_solver is None:
+            return Mi355Sat(workers=max(256, 1024 // width)) if cnf.n_clauses > 20000 else Mi355Sat()
+        try:
+            return make_solver(fraction=width)
+        except TypeError:            # a factory without the keyword: whatever it makes, `width` times
+            return make_solver()
+
+    def start(bound):
+        cnf = encoding.with_limits_into_cnf(PlatformLimits({(1, 1): bound}))
+        solver = make(cnf)
+        thunk, interrupter = run_solver(solver, cnf)
+        if on_interrupter:
+            on_interrupter(interrupter)
+        job = {"k": bound, "solver": solver, "intr": interrupter, "done": threading.Event(), "t0": time.perf_counter()}
+
+        def work():
+            try:
+                job["result"] = thunk()[0]
+            except Exception as e:        # surfaces in the caller's thread
+                job["error"] = e
+            job["seconds"] = time.perf_counter() - job["t0"]
+            job["done"].set()
+
+        job["thread"] = threading.Thread(target=work, daemon=True)
+        job["thread"].start()
+        jobs[bound] = job
+
+    def drop(bound):
+        job = jobs.pop(bound)
+        job["intr"].interrupt()
+        job["thread"].join()
+        job["solver"].close()
+
+    def drop_all():
+        for b in list(jobs):
+            drop(b)
+
+    def fill():
+        for b in range(front, max(front - width, refuted["k"]), -1):
+            if b >= 0 and b not in jobs:
+                start(b)
+
+    fill()
+    while True:
+        done = [b for b, j in jobs.items() if j["done"].is_set()]
+        if not done:
+            next(iter(jobs.values()))["done"].wait(0.005)
+            continue
+        b = min(done)                    # (the lowest answered bound says the most)
+        job = jobs.pop(b)
+        job["thread"].join()
+        if "error" in job:
+            drop_all()
+            job["solver"].close()
+            raise job["error"]
+        r = job["result"]
+        if r == SolverResult.Unsat:
+            job["solver"].close()
+            if b > refuted["k"]:
+                refuted["k"], refuted["seconds"] = b, job["seconds"]
+            for x in [x for x in jobs if x <= b]:
+                drop(x)
+            if b >= front:
+                history.append({"k": front, "result": r, "count": None, "valid": None, "seconds": job["seconds"], "stats": {}})
+                out("No solution found for the current constraints")
+                drop_all()
+                return history
+            continue
+        if r != SolverResult.Sat:        # interrupted from outside: the loop ends like the reference's
+            history.append({"k": front, "result": r, "count": None, "valid": None, "seconds": job["seconds"], "stats": job["solver"].stats()})
+            out("Solver interrupted")
+            job["solver"].close()
+            drop_all()
+            return history
+        rec = {"k": front, "result": r, "count": None, "valid": None, "seconds": job["seconds"], "stats": job["solver"].stats()}
+        history.append(rec)
+        layout = PlatformLayout.from_assignment(job["solver"].full_solution(encoding.n_vars), encoding)
+        job["solver"].close()
+        count = layout.platform_count()
+        rec["count"], rec["layout"] = count, layout
+        for x in [x for x in jobs if x >= count]:      # answered by this model
+            drop(x)
+        if count == 0:
+            out("Found a solution with no platforms - aborting")
+            drop_all()
+            return history
+        out(f"Solution found ({count} platforms total)")
+        for (w, h), n in sorted(layout.platform_stats().items()):
+            out(f"{w}x{h}: {n}")
+        rec["valid"] = layout.validate(grid).is_valid()
+        out("Solution validation OK" if rec["valid"] else "Solution validation FAILED")
+        front = count - 1
+        if front <= refuted["k"]:        # the next bound is refuted already
+            history.append({"k": front, "result": SolverResult.Unsat, "count": None, "valid": None, "seconds": refuted["seconds"], "stats": {}})
+            out("No solution found for the current constraints")
+            drop_all()
+            return history
+        fill()
+
+
 def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_interrupter=None, time_limit=None,
                       specialize_after=2.0, lookahead=False):
     """The same refinement as ONE batch: every bound k0, k0-1, ..., 0 is an assumption set over one
@@ -227,7 +345,7 @@ def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_in
 
     def on_deadline():
         expired.append(1)
-        for i in interrupters[-2:]:      # (with lookahead two solvers run at a time)
+        for i in interrupters[-max(2, int(lookahead)):]:      # (with lookahead several solvers run at a time)
             i.interrupt()
 
     if time_limit is not None:   # the rest of the time budget holds for the sequential part as a whole
@@ -235,7 +353,10 @@ def solver_loop_sweep(grid, encoding, limits, make_solver=None, out=print, on_in
         timer = threading.Timer(max(0.0, time_limit - (time.perf_counter() - t0)), on_deadline)
         timer.start()
     try:
-        if lookahead:
+        if lookahead is not True and int(lookahead) > 2:      # lookahead = N: N bounds at a time
+            rest = solver_loop_fan(grid, encoding, PlatformLimits({(1, 1): best - 1}), make_solver=make_solver, out=out, on_interrupter=note,
+                                   width=int(lookahead))
+        elif lookahead:
             rest = solver_loop_pair(grid, encoding, PlatformLimits({(1, 1): best - 1}), make_solver=make_solver, out=out, on_interrupter=note)
         else:
             rest = solver_loop(grid, encoding, PlatformLimits({(1, 1): best - 1}), make_solver=make_solver, out=out, on_interrupter=note)
